@@ -1,0 +1,743 @@
+/*
+ * innr_oracle.c -- CPU ORACLE (test infrastructure, NOT product code). See innr_oracle.h.
+ *
+ * Restates innr v0.6.3's *portable* CPU path. Arithmetic order is the contract:
+ * every loop below performs the same f32 operations in the same order as the cited
+ * Rust source, and this file must be compiled with -ffp-contract=off (Rust never
+ * fuses a*b+c). No fast-math, no reassociation.
+ */
+#include "innr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * total order
+ * ---------------------------------------------------------------------------------------- */
+
+/* core::f32::total_cmp: bits ^= ((bits >> 31) as u32 >> 1); compare as i32 */
+int32_t orc_total_key(float x) {
+    int32_t b;
+    memcpy(&b, &x, 4);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+
+/* <f32 as iter::Sum>::sum folds from -0.0 (rustc >= 1.83; the crate's MSRV is 1.89) */
+#define RUST_SUM_INIT (-0.0f)
+
+typedef struct {
+    uint64_t idx;
+    float score;
+} pair_t;
+
+/* returns nonzero if a must come strictly before b */
+typedef int (*before_fn)(const pair_t* a, const pair_t* b);
+
+/* sort_by(|a, b| b.1.total_cmp(&a.1)): descending */
+static int before_desc(const pair_t* a, const pair_t* b) {
+    return orc_total_key(a->score) > orc_total_key(b->score);
+}
+/* sort_by(|a, b| a.1.total_cmp(&b.1)): ascending */
+static int before_asc(const pair_t* a, const pair_t* b) {
+    return orc_total_key(a->score) < orc_total_key(b->score);
+}
+
+/* Stable merge sort (slice::sort_by is stable; any stable sort yields the same permutation). */
+static void merge_sort_rec(pair_t* a, pair_t* tmp, size_t n, before_fn before) {
+    if (n < 2) return;
+    if (n <= 16) { /* stable insertion sort */
+        for (size_t i = 1; i < n; ++i) {
+            pair_t x = a[i];
+            size_t j = i;
+            while (j > 0 && before(&x, &a[j - 1])) {
+                a[j] = a[j - 1];
+                --j;
+            }
+            a[j] = x;
+        }
+        return;
+    }
+    size_t h = n / 2;
+    merge_sort_rec(a, tmp, h, before);
+    merge_sort_rec(a + h, tmp, n - h, before);
+    size_t i = 0, j = h, o = 0;
+    while (i < h && j < n) {
+        /* take right only if it is strictly before left: keeps equal elements in input order */
+        if (before(&a[j], &a[i])) tmp[o++] = a[j++];
+        else tmp[o++] = a[i++];
+    }
+    while (i < h) tmp[o++] = a[i++];
+    while (j < n) tmp[o++] = a[j++];
+    memcpy(a, tmp, n * sizeof(pair_t));
+}
+
+static void stable_sort(pair_t* a, size_t n, before_fn before) {
+    if (n < 2) return;
+    pair_t* tmp = (pair_t*)malloc(n * sizeof(pair_t));
+    merge_sort_rec(a, tmp, n, before);
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * batch::VerticalBatch
+ * ---------------------------------------------------------------------------------------- */
+
+/* batch.rs:167-183 from_flat (same transpose as from_rows :103-131 / from_slices :138-164) */
+void orc_vb_from_flat(const float* rows, size_t n, size_t dim, float* out) {
+    for (size_t i = 0; i < n; ++i)
+        for (size_t d = 0; d < dim; ++d) out[d * n + i] = rows[i * dim + d];
+}
+
+/* batch.rs:217-219 */
+void orc_vb_extract_vector(const float* data, size_t n, size_t dim, size_t i, float* out) {
+    for (size_t d = 0; d < dim; ++d) out[d] = data[d * n + i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scans
+ * ---------------------------------------------------------------------------------------- */
+
+/* batch.rs:284-297: products.resize(N, 0.0); for d { for i { prod[i] += q_d * v } } */
+void orc_batch_dot(const float* q, const float* data, size_t n, size_t dim, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = 0.0f;
+    for (size_t d = 0; d < dim; ++d) {
+        const float qd = q[d];
+        const float* restrict row = data + d * n;
+        float* restrict o = out;
+        for (size_t i = 0; i < n; ++i) o[i] += qd * row[i];
+    }
+}
+
+/* batch.rs:250-266: diff = q_d - v_d; dist += diff*diff */
+void orc_batch_l2_squared(const float* q, const float* data, size_t n, size_t dim, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = 0.0f;
+    for (size_t d = 0; d < dim; ++d) {
+        const float qd = q[d];
+        const float* restrict row = data + d * n;
+        float* restrict o = out;
+        for (size_t i = 0; i < n; ++i) {
+            float diff = qd - row[i];
+            o[i] += diff * diff;
+        }
+    }
+}
+
+/* batch.rs:672-686: norm += v*v over d, then sqrt */
+void orc_batch_norms(const float* data, size_t n, size_t dim, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = 0.0f;
+    for (size_t d = 0; d < dim; ++d) {
+        const float* restrict row = data + d * n;
+        float* restrict o = out;
+        for (size_t i = 0; i < n; ++i) o[i] += row[i] * row[i];
+    }
+    for (size_t i = 0; i < n; ++i) out[i] = sqrtf(out[i]);
+}
+
+/* batch.rs:705-728 */
+void orc_batch_cosine(const float* q, const float* data, size_t n, size_t dim, const float* norms,
+                      float* out) {
+    orc_batch_dot(q, data, n, dim, out);
+    float ss = RUST_SUM_INIT; /* :714 query.iter().map(|x| x*x).sum::<f32>().sqrt() */
+    for (size_t d = 0; d < dim; ++d) ss += q[d] * q[d];
+    float qn = sqrtf(ss);
+    if (qn < ORC_NORM_EPSILON) { /* :716-719 */
+        for (size_t i = 0; i < n; ++i) out[i] = 0.0f;
+        return;
+    }
+    for (size_t i = 0; i < n; ++i) { /* :721-727 */
+        float nm = norms[i];
+        out[i] = (nm > ORC_NORM_EPSILON) ? out[i] / (qn * nm) : 0.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sort-based kNN
+ * ---------------------------------------------------------------------------------------- */
+
+static size_t sort_truncate_emit(const float* scores, size_t n, size_t k, before_fn before,
+                                 uint64_t* out_idx, float* out_score) {
+    pair_t* p = (pair_t*)malloc((n ? n : 1) * sizeof(pair_t));
+    for (size_t i = 0; i < n; ++i) {
+        p[i].idx = i;
+        p[i].score = scores[i];
+    }
+    stable_sort(p, n, before);
+    if (k > n) k = n;
+    for (size_t i = 0; i < k; ++i) {
+        out_idx[i] = p[i].idx;
+        out_score[i] = p[i].score;
+    }
+    free(p);
+    return k;
+}
+
+/* batch.rs:742-764 */
+size_t orc_batch_knn_dot(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                         uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    float* dots = (float*)malloc(n * sizeof(float));
+    orc_batch_dot(q, data, n, dim, dots);
+    size_t r = sort_truncate_emit(dots, n, k, before_desc, out_idx, out_score);
+    free(dots);
+    return r;
+}
+
+/* batch.rs:777-800 (norms recomputed per call, :788) */
+size_t orc_batch_knn_cosine(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                            uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    float* norms = (float*)malloc(n * sizeof(float));
+    float* cos = (float*)malloc(n * sizeof(float));
+    orc_batch_norms(data, n, dim, norms);
+    orc_batch_cosine(q, data, n, dim, norms, cos);
+    size_t r = sort_truncate_emit(cos, n, k, before_desc, out_idx, out_score);
+    free(norms);
+    free(cos);
+    return r;
+}
+
+/* batch.rs:572-592 */
+void orc_batch_dimension_variance(const float* data, size_t n, size_t dim, float* out_var) {
+    if (n <= 1 || dim == 0) {
+        for (size_t d = 0; d < dim; ++d) out_var[d] = 0.0f;
+        return;
+    }
+    float nf = (float)n;
+    for (size_t d = 0; d < dim; ++d) {
+        const float* row = data + d * n;
+        float s = RUST_SUM_INIT;
+        for (size_t i = 0; i < n; ++i) s += row[i];
+        float mean = s / nf;
+        float v = RUST_SUM_INIT;
+        for (size_t i = 0; i < n; ++i) v += (row[i] - mean) * (row[i] - mean);
+        out_var[d] = v / nf;
+    }
+}
+
+/* batch.rs:621-659 (variance_order :599-603: stable sort of dims by variance descending) */
+size_t orc_batch_knn_reordered(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                               uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    float* var = (float*)malloc((dim ? dim : 1) * sizeof(float));
+    orc_batch_dimension_variance(data, n, dim, var);
+    pair_t* ord = (pair_t*)malloc((dim ? dim : 1) * sizeof(pair_t));
+    for (size_t d = 0; d < dim; ++d) {
+        ord[d].idx = d;
+        ord[d].score = var[d];
+    }
+    stable_sort(ord, dim, before_desc);
+    float* dist = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) dist[i] = 0.0f;
+    for (size_t t = 0; t < dim; ++t) {
+        size_t d = (size_t)ord[t].idx;
+        float qd = q[d];
+        const float* row = data + d * n;
+        for (size_t i = 0; i < n; ++i) {
+            float diff = qd - row[i];
+            dist[i] += diff * diff;
+        }
+    }
+    size_t r = sort_truncate_emit(dist, n, k, before_asc, out_idx, out_score);
+    free(var);
+    free(ord);
+    free(dist);
+    return r;
+}
+
+/* batch.rs:820-882 */
+size_t orc_batch_knn_filtered(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                              const uint8_t* mask, uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    size_t passing = 0;
+    for (size_t i = 0; i < n; ++i) passing += mask[i] ? 1 : 0;
+    if (passing == 0) return 0;
+    if (k > passing) k = passing;
+    float* dist = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) dist[i] = mask[i] ? 0.0f : 3.40282347e+38f; /* f32::MAX :855 */
+    for (size_t d = 0; d < dim; ++d) {
+        float qd = q[d];
+        const float* row = data + d * n;
+        for (size_t i = 0; i < n; ++i) {
+            if (mask[i]) {
+                float diff = qd - row[i];
+                dist[i] += diff * diff;
+            }
+        }
+    }
+    pair_t* p = (pair_t*)malloc(passing * sizeof(pair_t));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (mask[i]) {
+            p[m].idx = i;
+            p[m].score = dist[i];
+            ++m;
+        }
+    stable_sort(p, m, before_asc);
+    for (size_t i = 0; i < k; ++i) {
+        out_idx[i] = p[i].idx;
+        out_score[i] = p[i].score;
+    }
+    free(p);
+    free(dist);
+    return k;
+}
+
+/* batch.rs:320-365 */
+size_t orc_batch_l2_squared_pruning(const float* q, const float* data, size_t n, size_t dim,
+                                    float threshold, uint64_t* out_idx, float* out_dist) {
+    float* dist = (float*)calloc(n ? n : 1, sizeof(float));
+    uint8_t* alive = (uint8_t*)malloc(n ? n : 1);
+    memset(alive, 1, n);
+    size_t num_alive = n;
+    for (size_t d = 0; d < dim; ++d) {
+        if (num_alive == 0) break;
+        float qd = q[d];
+        const float* row = data + d * n;
+        for (size_t i = 0; i < n; ++i) {
+            if (!alive[i]) continue;
+            float diff = qd - row[i];
+            dist[i] += diff * diff;
+            if (dist[i] > threshold) {
+                alive[i] = 0;
+                --num_alive;
+            }
+        }
+    }
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (alive[i]) {
+            out_idx[m] = i;
+            out_dist[m] = dist[i];
+            ++m;
+        }
+    free(dist);
+    free(alive);
+    return m;
+}
+
+static int cmp_key_asc(const void* a, const void* b) {
+    int32_t ka = orc_total_key(*(const float*)a), kb = orc_total_key(*(const float*)b);
+    return (ka > kb) - (ka < kb);
+}
+
+/* batch.rs:441-564 (approximate, heuristic; CPU-only in the new build as well) */
+size_t orc_batch_knn_adaptive(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                              size_t warmup_dims, uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    if (dim == 0) { /* :458-463 */
+        for (size_t i = 0; i < k; ++i) {
+            out_idx[i] = i;
+            out_score[i] = 0.0f;
+        }
+        return k;
+    }
+    if (warmup_dims > dim) warmup_dims = dim;
+    float* dist = (float*)calloc(n, sizeof(float));
+    uint8_t* alive = (uint8_t*)malloc(n);
+    memset(alive, 1, n);
+    size_t alive_count = n;
+    for (size_t d = 0; d < warmup_dims; ++d) { /* :471-478 */
+        float qd = q[d];
+        const float* row = data + d * n;
+        for (size_t i = 0; i < n; ++i) {
+            float diff = qd - row[i];
+            dist[i] += diff * diff;
+        }
+    }
+    float scale = (float)dim / (float)warmup_dims;
+    float* buf = (float*)malloc(n * sizeof(float));
+    memcpy(buf, dist, n * sizeof(float));
+    qsort(buf, n, sizeof(float), cmp_key_asc); /* value of the (k-1)-th order statistic only */
+    float threshold = buf[k - 1] * scale;      /* :483-487 (k <= n always holds here) */
+    for (size_t i = 0; i < n; ++i) {           /* :490-498 */
+        float est = dist[i] * scale;
+        if (alive_count > k && est > threshold * 1.5f) {
+            alive[i] = 0;
+            --alive_count;
+        }
+    }
+    for (size_t d = warmup_dims; d < dim; ++d) { /* :504-547 */
+        float qd = q[d];
+        const float* row = data + d * n;
+        for (size_t i = 0; i < n; ++i) {
+            if (!alive[i]) continue;
+            float diff = qd - row[i];
+            dist[i] += diff * diff;
+            if (alive_count > k && dist[i] > threshold) {
+                alive[i] = 0;
+                --alive_count;
+            }
+        }
+        if (d % 32 == 0) {
+            size_t count = 0;
+            for (size_t i = 0; i < n; ++i)
+                if (alive[i]) buf[count++] = dist[i];
+            if (count >= k) {
+                qsort(buf, count, sizeof(float), cmp_key_asc); /* select_nth_unstable(k-1) value */
+                threshold = buf[k - 1];
+            }
+        }
+    }
+    pair_t* p = (pair_t*)malloc(n * sizeof(pair_t));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (alive[i]) {
+            p[m].idx = i;
+            p[m].score = dist[i];
+            ++m;
+        }
+    stable_sort(p, m, before_asc);
+    if (k > m) k = m;
+    for (size_t i = 0; i < k; ++i) {
+        out_idx[i] = p[i].idx;
+        out_score[i] = p[i].score;
+    }
+    free(p);
+    free(buf);
+    free(dist);
+    free(alive);
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * topk::TopK -- buffer sorted DESCENDING by distance, worst at index 0 (topk.rs:47-55)
+ * ---------------------------------------------------------------------------------------- */
+struct orc_topk {
+    size_t k;
+    size_t count;
+    float* dist;
+    uint32_t* ids;
+};
+
+orc_topk* orc_topk_new(size_t k) {
+    if (k == 0) return NULL; /* reference: assert!(k > 0) topk.rs:65 */
+    orc_topk* t = (orc_topk*)malloc(sizeof(orc_topk));
+    t->k = k;
+    t->count = 0;
+    t->dist = (float*)malloc(k * sizeof(float));
+    t->ids = (uint32_t*)malloc(k * sizeof(uint32_t));
+    return t;
+}
+
+void orc_topk_free(orc_topk* t) {
+    if (!t) return;
+    free(t->dist);
+    free(t->ids);
+    free(t);
+}
+
+float orc_topk_threshold(const orc_topk* t) { /* topk.rs:80-87 */
+    return (t->count < t->k) ? INFINITY : t->dist[0];
+}
+
+size_t orc_topk_len(const orc_topk* t) { return t->count; }
+
+/*
+ * topk.rs:171-186 find_insert_pos = slice.binary_search_by(|d| d.total_cmp(&distance).reverse()),
+ * Ok(i)|Err(i) => i. Which index comes back among EQUAL elements is a property of core's
+ * binary_search_by, not of innr; this mirrors core's branch-light loop (Rust >= 1.82): base moves to
+ * mid unless the probe compares Greater, so the LAST not-Greater element decides.
+ */
+static size_t topk_find_insert_pos(const orc_topk* t, float distance, size_t len) {
+    if (len == 0) return 0;
+    int32_t kd = orc_total_key(distance);
+    size_t size = len, base = 0;
+    /* cmp(elem) = elem.total_cmp(distance).reverse(): Greater  <=> elem < distance */
+    while (size > 1) {
+        size_t half = size / 2, mid = base + half;
+        int32_t ke = orc_total_key(t->dist[mid]);
+        int greater = ke < kd;
+        base = greater ? base : mid;
+        size -= half;
+    }
+    int32_t ke = orc_total_key(t->dist[base]);
+    if (ke == kd) return base;          /* Ok(base) */
+    return base + ((ke > kd) ? 1 : 0);  /* Err(base + (cmp == Less)) ; Less <=> elem > distance */
+}
+
+void orc_topk_insert(orc_topk* t, uint32_t id, float distance) { /* topk.rs:96-121 */
+    if (t->count < t->k) {
+        size_t pos = topk_find_insert_pos(t, distance, t->count); /* insert_sorted :153-163 */
+        memmove(t->dist + pos + 1, t->dist + pos, (t->count - pos) * sizeof(float));
+        memmove(t->ids + pos + 1, t->ids + pos, (t->count - pos) * sizeof(uint32_t));
+        t->dist[pos] = distance;
+        t->ids[pos] = id;
+        t->count += 1;
+    } else if (orc_total_key(distance) < orc_total_key(t->dist[0])) { /* strict less :101 */
+        memmove(t->dist, t->dist + 1, (t->k - 1) * sizeof(float));
+        memmove(t->ids, t->ids + 1, (t->k - 1) * sizeof(uint32_t));
+        size_t pos = topk_find_insert_pos(t, distance, t->k - 1);
+        memmove(t->dist + pos + 1, t->dist + pos, (t->k - 1 - pos) * sizeof(float));
+        memmove(t->ids + pos + 1, t->ids + pos, (t->k - 1 - pos) * sizeof(uint32_t));
+        t->dist[pos] = distance;
+        t->ids[pos] = id;
+    }
+}
+
+size_t orc_topk_into_sorted(orc_topk* t, uint32_t* ids, float* dists) { /* topk.rs:140-145 */
+    for (size_t i = 0; i < t->count; ++i) {
+        ids[i] = t->ids[t->count - 1 - i];
+        dists[i] = t->dist[t->count - 1 - i];
+    }
+    return t->count;
+}
+
+/* batch.rs:385-411 */
+size_t orc_batch_knn(const float* q, const float* data, size_t n, size_t dim, size_t k,
+                     uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n;
+    float* dist = (float*)malloc(n * sizeof(float));
+    orc_batch_l2_squared(q, data, n, dim, dist);
+    orc_topk* t = orc_topk_new(k);
+    for (size_t i = 0; i < n; ++i) orc_topk_insert(t, (uint32_t)i, dist[i]); /* `i as u32` :403 */
+    uint32_t* ids = (uint32_t*)malloc(k * sizeof(uint32_t));
+    size_t r = orc_topk_into_sorted(t, ids, out_score);
+    for (size_t i = 0; i < r; ++i) out_idx[i] = ids[i];
+    free(ids);
+    orc_topk_free(t);
+    free(dist);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dense portable pairwise kernels
+ * ---------------------------------------------------------------------------------------- */
+
+/* dense.rs:103-125: 4 strided accumulators, ((s0+s1)+s2)+s3, then sequential tail */
+float orc_dot_portable(const float* a, const float* b, size_t n) {
+    size_t chunks = n / 4;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t base = i * 4;
+        s0 += a[base] * b[base];
+        s1 += a[base + 1] * b[base + 1];
+        s2 += a[base + 2] * b[base + 2];
+        s3 += a[base + 3] * b[base + 3];
+    }
+    float r = s0 + s1 + s2 + s3;
+    for (size_t i = chunks * 4; i < n; ++i) r += a[i] * b[i];
+    return r;
+}
+
+/* dense.rs:288-346: guards compare SQUARED norms with NORM_EPSILON_SQ */
+float orc_cosine_portable(const float* a, const float* b, size_t n) {
+    size_t chunks = n / 4;
+    float ab[4] = {0, 0, 0, 0}, aa[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t base = i * 4;
+        for (int j = 0; j < 4; ++j) {
+            float x = a[base + j], y = b[base + j];
+            ab[j] += x * y;
+            aa[j] += x * x;
+            bb[j] += y * y;
+        }
+    }
+    float sab = ab[0] + ab[1] + ab[2] + ab[3];
+    float saa = aa[0] + aa[1] + aa[2] + aa[3];
+    float sbb = bb[0] + bb[1] + bb[2] + bb[3];
+    for (size_t i = chunks * 4; i < n; ++i) {
+        float x = a[i], y = b[i];
+        sab += x * y;
+        saa += x * x;
+        sbb += y * y;
+    }
+    if (saa > ORC_NORM_EPSILON_SQ && sbb > ORC_NORM_EPSILON_SQ) return sab / (sqrtf(saa) * sqrtf(sbb));
+    return 0.0f;
+}
+
+/* dense.rs:648-675 */
+float orc_l2_distance_squared_portable(const float* a, const float* b, size_t n) {
+    size_t chunks = n / 4;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t base = i * 4;
+        float d0 = a[base] - b[base], d1 = a[base + 1] - b[base + 1];
+        float d2 = a[base + 2] - b[base + 2], d3 = a[base + 3] - b[base + 3];
+        s0 += d0 * d0;
+        s1 += d1 * d1;
+        s2 += d2 * d2;
+        s3 += d3 * d3;
+    }
+    float r = s0 + s1 + s2 + s3;
+    for (size_t i = chunks * 4; i < n; ++i) {
+        float d = a[i] - b[i];
+        r += d * d;
+    }
+    return r;
+}
+
+/* dense.rs:550-572 */
+float orc_l1_distance_portable(const float* a, const float* b, size_t n) {
+    size_t chunks = n / 4;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (size_t i = 0; i < chunks; ++i) {
+        size_t base = i * 4;
+        s0 += fabsf(a[base] - b[base]);
+        s1 += fabsf(a[base + 1] - b[base + 1]);
+        s2 += fabsf(a[base + 2] - b[base + 2]);
+        s3 += fabsf(a[base + 3] - b[base + 3]);
+    }
+    float r = s0 + s1 + s2 + s3;
+    for (size_t i = chunks * 4; i < n; ++i) r += fabsf(a[i] - b[i]);
+    return r;
+}
+
+/* distance.rs:73-114 */
+float orc_dist_cosine(const float* a, const float* b, size_t n) { return 1.0f - orc_cosine_portable(a, b, n); }
+float orc_dist_dot(const float* a, const float* b, size_t n) { return -orc_dot_portable(a, b, n); }
+float orc_dist_l2(const float* a, const float* b, size_t n) { return sqrtf(orc_l2_distance_squared_portable(a, b, n)); }
+float orc_dist_l1(const float* a, const float* b, size_t n) { return orc_l1_distance_portable(a, b, n); }
+
+/* ------------------------------------------------------------------------------------------
+ * maxsim (portable path maxsim.rs:142-152; cosine variant :168-194)
+ * f32::max ignores a NaN operand (returns the other) == C fmaxf.
+ * ---------------------------------------------------------------------------------------- */
+float orc_maxsim(const float* q, size_t nq, const float* d, size_t nd, size_t dim) {
+    if (nq == 0 || nd == 0) return 0.0f; /* maxsim.rs:97-99 */
+    float total = RUST_SUM_INIT;
+    for (size_t i = 0; i < nq; ++i) {
+        float m = -INFINITY;
+        for (size_t j = 0; j < nd; ++j) m = fmaxf(m, orc_dot_portable(q + i * dim, d + j * dim, dim));
+        total += m;
+    }
+    return total;
+}
+
+float orc_maxsim_cosine(const float* q, size_t nq, const float* d, size_t nd, size_t dim) {
+    if (nq == 0 || nd == 0) return 0.0f;
+    float total = RUST_SUM_INIT;
+    for (size_t i = 0; i < nq; ++i) {
+        float m = -INFINITY;
+        for (size_t j = 0; j < nd; ++j) m = fmaxf(m, orc_cosine_portable(q + i * dim, d + j * dim, dim));
+        total += m;
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * scalar: affine u8 quantisation
+ * ---------------------------------------------------------------------------------------- */
+orc_qparams orc_qparams_from_range(float min, float max) { /* scalar.rs:54-60 */
+    orc_qparams p;
+    float alpha = max - min;
+    p.alpha = (alpha > 0.0f) ? alpha : 1.0f;
+    p.offset = min;
+    return p;
+}
+
+orc_qparams orc_qparams_fit(const float* values, size_t n) { /* scalar.rs:68-87 */
+    if (n == 0) {
+        orc_qparams p = {1.0f, 0.0f};
+        return p;
+    }
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    for (size_t i = 0; i < n; ++i) {
+        float v = values[i];
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    return orc_qparams_from_range(mn, mx);
+}
+
+orc_qparams orc_qparams_fit_quantile(const float* values, size_t n, float quantile) { /* :104-139 */
+    orc_qparams dflt = {1.0f, 0.0f};
+    if (n == 0) return dflt;
+    if (quantile >= 1.0f) return orc_qparams_fit(values, n);
+    float* s = (float*)malloc(n * sizeof(float));
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (isfinite(values[i])) s[m++] = values[i];
+    if (m == 0) {
+        free(s);
+        return dflt;
+    }
+    qsort(s, m, sizeof(float), cmp_key_asc);
+    float tail = (1.0f - quantile) / 2.0f;
+    size_t lo = (size_t)floorf(tail * (float)m);
+    size_t hi = (size_t)ceilf((1.0f - tail) * (float)m);
+    if (hi > m - 1) hi = m - 1;
+    orc_qparams p = orc_qparams_from_range(s[lo], s[hi]);
+    free(s);
+    return p;
+}
+
+/* scalar.rs:212-225: round() is half-away-from-zero (roundf); `as u8` saturates, NaN -> 0 */
+void orc_quantize_u8(const float* values, size_t n, orc_qparams p, uint8_t* out) {
+    float inv_alpha = 255.0f / p.alpha;
+    for (size_t i = 0; i < n; ++i) {
+        float normalized = (values[i] - p.offset) * inv_alpha;
+        float r = roundf(normalized);
+        if (isnan(r)) out[i] = 0;
+        else if (r < 0.0f) out[i] = 0;
+        else if (r > 255.0f) out[i] = 255;
+        else out[i] = (uint8_t)r;
+    }
+}
+
+float orc_query_sum(const float* q, size_t n) { /* scalar.rs:236-240 */
+    float s = RUST_SUM_INIT;
+    for (size_t i = 0; i < n; ++i) s += q[i];
+    return s;
+}
+
+float orc_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n) { /* scalar.rs:353-358 */
+    float s = RUST_SUM_INIT;
+    for (size_t i = 0; i < n; ++i) s += a[i] * (float)b[i];
+    return s;
+}
+
+/* scalar.rs:284-300: (alpha / 255.0) * mixed + offset * query_sum */
+static float asym_precomputed(const float* q, const uint8_t* codes, size_t n, orc_qparams p, float qsum) {
+    float mixed = orc_mixed_dot_u8_f32(q, codes, n);
+    return (p.alpha / 255.0f) * mixed + p.offset * qsum;
+}
+
+float orc_asymmetric_dot_u8(const float* q, const uint8_t* codes, size_t n, orc_qparams p) {
+    return asym_precomputed(q, codes, n, p, orc_query_sum(q, n));
+}
+
+/* scalar.rs:370-393 */
+size_t orc_batch_knn_u8(const float* q, const uint8_t* codes, size_t n, size_t dim, orc_qparams p,
+                        size_t k, uint64_t* out_idx, float* out_score) {
+    if (n == 0 || k == 0) return 0;
+    float qsum = orc_query_sum(q, dim);
+    if (k > n) k = n;
+    float* sc = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) sc[i] = asym_precomputed(q, codes + i * dim, dim, p, qsum);
+    size_t r = sort_truncate_emit(sc, n, k, before_desc, out_idx, out_score);
+    free(sc);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * generators (examples/batch_demo.rs:233-242, examples/maxsim_colbert.rs:212-228)
+ * ---------------------------------------------------------------------------------------- */
+void orc_generate_embedding(size_t dim, uint64_t seed, float* out) {
+    for (size_t i = 0; i < dim; ++i) {
+        uint64_t x = seed * 6364136223846793005ULL + (uint64_t)i * 1442695040888963407ULL;
+        out[i] = ((float)(x >> 33) / 2147483648.0f) * 2.0f - 1.0f;
+    }
+}
+
+void orc_generate_normalized(size_t dim, uint64_t seed, float* out) {
+    orc_generate_embedding(dim, seed, out);
+    float ss = RUST_SUM_INIT;
+    for (size_t i = 0; i < dim; ++i) ss += out[i] * out[i];
+    float norm = sqrtf(ss);
+    if (norm > 1.1920929e-07f) /* f32::EPSILON */
+        for (size_t i = 0; i < dim; ++i) out[i] /= norm;
+}
+
+void orc_generate_rows(size_t n, size_t dim, uint64_t seed0, int normalized, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        if (normalized) orc_generate_normalized(dim, seed0 + i, out + i * dim);
+        else orc_generate_embedding(dim, seed0 + i, out + i * dim);
+    }
+}

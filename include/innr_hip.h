@@ -1,0 +1,124 @@
+/*
+ * innr_hip.h -- C ABI of the MI355X-native (gfx950 / CDNA4) batch k-NN scan behind innr's API.
+ *
+ * This is the drop-in boundary for ONE path of arclabs561/innr: batch::VerticalBatch +
+ * batch_dot / batch_l2_squared / batch_cosine / batch_norms / batch_knn_* (src/batch.rs),
+ * scalar::batch_knn_u8 (src/scalar.rs) and maxsim (src/maxsim.rs). The reference has no FFI of
+ * its own (pure Rust, zero deps); these entry points are what a Rust `extern "C"` shim for that
+ * path binds -- each one cites the reference interface it replaces. INTEGRATION.md shows the shim.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; every function returns an innr_status
+ *     (0 = ok, <0 = error) and never throws or aborts across the ABI. innr_last_error() returns a
+ *     thread-local message for the last failure.
+ *   - the reference reports misuse by panicking (assert_eq! on dimension mismatch, batch.rs:251,285,
+ *     386,743,778); the ABI returns INNR_E_DIM_MISMATCH and the host shim turns it into that panic.
+ *   - host buffers are caller-owned and only read/written during the call. `_dev` variants take
+ *     DEVICE pointers (hipMalloc'ed / torch tensors on the ctx's device), run on the ctx stream and
+ *     return after the result is complete on that stream.
+ *   - indices are reported as uint64 (Rust usize); on device they are u32 (N < 2^32 - 1 per shard)
+ *     plus a 64-bit per-shard base (innr_batch_set_index_base) for range-partitioned corpora.
+ *   - results are deterministic: same inputs => same bits (tests/integration.rs:134-151).
+ *   - there is NO CPU fallback inside this library. If no GPU is present, innr_ctx_create fails.
+ */
+#ifndef INNR_HIP_H
+#define INNR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int innr_status;
+#define INNR_OK 0
+#define INNR_E_DIM_MISMATCH (-1) /* reference: assert_eq!(query.len(), batch.dimension) panics */
+#define INNR_E_BAD_ARG (-2)
+#define INNR_E_OOM (-3)
+#define INNR_E_HIP (-4)
+#define INNR_E_RCCL (-5)
+#define INNR_E_UNSUPPORTED (-6) /* documented limit of this build (e.g. k > INNR_MAX_K) */
+
+/* metric selector: which reference function family a scan/kNN call reproduces */
+#define INNR_METRIC_DOT 0    /* batch_dot / batch_knn_dot            batch.rs:270-297, 742-764 (higher = better) */
+#define INNR_METRIC_L2SQ 1   /* batch_l2_squared / batch_knn         batch.rs:236-266, 385-411 (lower = better)  */
+#define INNR_METRIC_COSINE 2 /* batch_cosine / batch_knn_cosine      batch.rs:690-728, 777-800 (higher = better) */
+
+/* kNN engine selector */
+#define INNR_KNN_AUTO 0  /* MFMA GEMM for query batches, exact scan for small batches */
+#define INNR_KNN_EXACT 1 /* bit-exact VALU scan in the reference's arithmetic order (HBM-bound) */
+#define INNR_KNN_MFMA 2  /* f32 MFMA GEMM + fused top-k filter + exact re-score (MFMA-bound) */
+
+#define INNR_MAX_K 240 /* largest k one call supports (device candidate lists hold k + margin <= 256) */
+
+typedef struct innr_ctx innr_ctx;     /* one GPU: device id, stream, workspace. One per process/GPU. */
+typedef struct innr_batch innr_batch; /* device-resident VerticalBatch (PDX, dimension-major) + cached norms */
+
+/* what a kNN call did (optional out-parameter; all fields written) */
+typedef struct innr_knn_stats {
+    int engine;                 /* INNR_KNN_EXACT or INNR_KNN_MFMA actually used */
+    uint32_t queries_fallback;  /* MFMA engine: queries whose margin proof failed and were redone exactly */
+    uint32_t candidates_kept;   /* k' = candidates per query kept before the exact re-score */
+    float gemm_ms;              /* device time of the dominant kernel (HIP events on the ctx stream) */
+    float total_ms;             /* device time of the whole call */
+} innr_knn_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+innr_status innr_ctx_create(int device, innr_ctx** out);
+void innr_ctx_destroy(innr_ctx* ctx);
+/* run on an existing HIP stream (hipStream_t as void*), e.g. torch's current stream; NULL = own stream */
+innr_status innr_ctx_set_stream(innr_ctx* ctx, void* hip_stream);
+innr_status innr_ctx_synchronize(innr_ctx* ctx);
+const char* innr_last_error(void);
+const char* innr_version(void);
+
+/* ---- VerticalBatch (batch.rs:88-220) -------------------------------------------------------- */
+/* data = VerticalBatch::data() (batch.rs:212): dimension-major, data[d*N + i] */
+innr_status innr_batch_upload_colmajor(innr_ctx* ctx, const float* data, size_t N, size_t D, innr_batch** out);
+/* rows = what from_rows/from_slices/from_flat receive (batch.rs:103,138,167): row-major [N*D];
+ * the row-major -> dimension-major transpose runs on the device */
+innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t N, size_t D, innr_batch** out);
+/* synthetic corpus generated on the device: row i = generate_embedding(D, seed0 + i)
+ * (examples/batch_demo.rs:167-170, 233-242). Used by the bench (30 GB cannot cross PCIe per run). */
+innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, uint64_t seed0, innr_batch** out);
+void innr_batch_free(innr_batch* b);
+size_t innr_batch_num_vectors(const innr_batch* b); /* batch.rs:199 */
+size_t innr_batch_dimension(const innr_batch* b);   /* batch.rs:204 */
+/* copy the dimension-major data back (VerticalBatch::data(), batch.rs:212): out[D*N] */
+innr_status innr_batch_download_colmajor(innr_batch* b, float* out);
+/* range-partitioned corpus: reported index = base + local index */
+innr_status innr_batch_set_index_base(innr_batch* b, uint64_t base);
+
+/* ---- one query x N scans (bit-identical to the reference's loops) --------------------------- */
+/* batch_dot_into / batch_l2_squared_into / batch_cosine_into (batch.rs:284,250,705).
+ * q: [D]; out: [N]. COSINE: `norms` = the caller's batch_norms() result [N] as in the reference
+ * signature (batch.rs:690), or NULL to use the norms cached on the device. */
+innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t D, const float* norms, float* out);
+/* batch_norms_into (batch.rs:672): out[N] */
+innr_status innr_batch_norms(innr_batch* b, float* out);
+
+/* ---- kNN ------------------------------------------------------------------------------------ */
+/* batch_knn_dot / batch_knn_cosine / batch_knn for Q queries at once (Q = 1 is the reference call).
+ * queries: row-major [Q*D]. Writes k' = min(k, N) results per query, best first, to
+ * out_idx[q*k' + r], out_score[q*k' + r]; *out_k = k'. k == 0 or N == 0 => *out_k = 0 (batch.rs:745).
+ * Ordering: DOT/COSINE score descending by f32::total_cmp, ties -> lower index (stable sort,
+ * batch.rs:757,793); L2SQ distance ascending, ties -> lower index (TopK keeps earlier ids, topk.rs:101).
+ * Scores are bit-identical to the reference's portable loops in every engine. */
+innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, size_t k,
+                           int engine, uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats);
+/* same, queries and outputs resident on the device (out arrays sized Q*min(k,N)) */
+innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D, size_t k,
+                               int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
+                               innr_knn_stats* stats);
+
+/* ---- multi-GPU merge (range partition + all-gather of per-shard top-k) --------- */
+/* in: G shards x Q queries x kin candidates (device pointers, layout [g][q][kin], global indices);
+ * out: best kout per query by (score order of `metric`, index ascending). */
+innr_status innr_merge_topk_dev(innr_ctx* ctx, int metric, const uint64_t* d_idx, const float* d_score, size_t G,
+                                size_t Q, size_t kin, size_t kout, uint64_t* d_out_idx, float* d_out_score);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INNR_HIP_H */

@@ -1,0 +1,155 @@
+"""ctypes binding of the C ABI (include/innr_hip.h) -> innr_amd/lib/libinnr_hip.so.
+
+There is no CPU fallback anywhere in this package: if the shared library is missing, or no GPU is
+visible, every operation raises. (The CPU oracle under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libinnr_hip.so")
+
+OK = 0
+E_DIM_MISMATCH = -1
+E_BAD_ARG = -2
+E_OOM = -3
+E_HIP = -4
+E_RCCL = -5
+E_UNSUPPORTED = -6
+
+METRIC_DOT = 0
+METRIC_L2SQ = 1
+METRIC_COSINE = 2
+
+KNN_AUTO = 0
+KNN_EXACT = 1
+KNN_MFMA = 2
+
+MAX_K = 240
+
+
+class InnrError(RuntimeError):
+    """A failure reported by the HIP library (status < 0 other than a dimension mismatch)."""
+
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"innr_hip status {status}: {msg}")
+        self.status = status
+
+
+class InnrPanic(AssertionError):
+    """What the reference reports by panicking (assert_eq!/assert!): same condition, Python exception."""
+
+
+class KnnStats(C.Structure):
+    _fields_ = [("engine", C.c_int), ("queries_fallback", C.c_uint32), ("candidates_kept", C.c_uint32),
+                ("gemm_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_szp = C.POINTER(C.c_size_t)
+_vp = C.c_void_p
+_sz = C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/innr_hip.h declares (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "innr_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "innr_ctx_destroy": (None, [_vp]),
+    "innr_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "innr_ctx_synchronize": (C.c_int, [_vp]),
+    "innr_last_error": (C.c_char_p, []),
+    "innr_version": (C.c_char_p, []),
+    "innr_batch_upload_colmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
+    "innr_batch_upload_rowmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
+    "innr_batch_generate": (C.c_int, [_vp, _sz, _sz, C.c_uint64, C.POINTER(_vp)]),
+    "innr_batch_free": (None, [_vp]),
+    "innr_batch_num_vectors": (_sz, [_vp]),
+    "innr_batch_dimension": (_sz, [_vp]),
+    "innr_batch_download_colmajor": (C.c_int, [_vp, _vp]),
+    "innr_batch_set_index_base": (C.c_int, [_vp, C.c_uint64]),
+    "innr_batch_scores": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _vp]),
+    "innr_batch_norms": (C.c_int, [_vp, _vp]),
+    "innr_batch_knn": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_batch_knn_dev": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_merge_topk_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load libinnr_hip.so (built by __graft_entry__.build() / innr_amd/csrc/Makefile). Raises if absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). innr_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+        return L
+
+
+def last_error() -> str:
+    return load().innr_last_error().decode("utf-8", "replace")
+
+
+def check(status: int) -> None:
+    if status == OK:
+        return
+    msg = last_error()
+    if status == E_DIM_MISMATCH:
+        raise InnrPanic(msg)
+    raise InnrError(status, msg)
+
+
+class Context:
+    """One GPU (innr_ctx). One per process in the multi-GPU layout (one process per GPU)."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = _vp()
+        check(L.innr_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def set_stream(self, stream_ptr: int | None) -> None:
+        check(load().innr_ctx_set_stream(self.handle, _vp(stream_ptr or 0)))
+
+    def synchronize(self) -> None:
+        check(load().innr_ctx_synchronize(self.handle))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            load().innr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    """Process-wide context on LOCAL_RANK's GPU (or device 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("INNR_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx

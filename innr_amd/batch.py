@@ -1,0 +1,281 @@
+"""Host-side mirror of innr's `batch` module (reference: src/batch.rs) over the HIP C ABI.
+
+Same function names, argument meaning and error behaviour as the reference:
+  VerticalBatch (batch.rs:88-220), batch_dot/_into (:270,:284), batch_l2_squared/_into (:236,:250),
+  batch_norms/_into (:663,:672), batch_cosine/_into (:690,:705), batch_knn (:385), batch_knn_dot (:742),
+  batch_knn_cosine (:777), BatchKnnResult (:368-377).
+A reference panic (assert_eq! on a dimension mismatch) is raised as InnrPanic (an AssertionError).
+Vec<f32> <-> numpy float32 arrays; `_into` variants refill a caller-owned Python list in place.
+
+Additions (the reference has no multi-query API; parity = "the reference called in a loop"):
+  batch_knn_dot_multi / batch_knn_cosine_multi / batch_knn_multi.
+
+Every computation runs on the GPU through include/innr_hip.h; nothing here computes scores on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (KNN_AUTO, METRIC_COSINE, METRIC_DOT, METRIC_L2SQ, InnrPanic, KnnStats, check, default_context,
+                   load)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _vp(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class VerticalBatch:
+    """Vertical (columnar, PDX) storage: data[d * num_vectors + i] (batch.rs:88-95), resident on the GPU."""
+
+    def __init__(self, handle: C.c_void_p, num_vectors: int, dimension: int, ctx: _lib.Context):
+        self._h = handle
+        self._n = int(num_vectors)
+        self._d = int(dimension)
+        self._ctx = ctx
+        self._host: Optional[np.ndarray] = None  # lazily downloaded dimension-major copy
+
+    # ---- constructors --------------------------------------------------------------------------
+    @classmethod
+    def _upload(cls, fn_name: str, arr: np.ndarray, n: int, d: int, ctx: Optional[_lib.Context]):
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(getattr(load(), fn_name)(ctx.handle, _vp(arr) if arr.size else None, n, d, C.byref(h)))
+        return cls(h, n, d, ctx)
+
+    @classmethod
+    def from_rows(cls, vectors: Sequence[Sequence[float]], ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """batch.rs:103-131. Panics on inconsistent vector dimension (batch.rs:120)."""
+        rows = [np.asarray(v, dtype=np.float32).reshape(-1) for v in vectors]
+        if len(rows) == 0:
+            return cls._upload("innr_batch_upload_rowmajor", np.empty(0, np.float32), 0, 0, ctx)
+        d = rows[0].size
+        for r in rows:
+            if r.size != d:
+                raise InnrPanic("Inconsistent vector dimension")
+        flat = np.ascontiguousarray(np.stack(rows)) if d else np.empty(0, np.float32)
+        return cls._upload("innr_batch_upload_rowmajor", flat, len(rows), d, ctx)
+
+    from_slices = from_rows  # batch.rs:138-164: same contract for borrowed slices
+
+    @classmethod
+    def from_flat(cls, data, num_vectors: int, dimension: int, ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """batch.rs:167-183: flat row-major data; asserts len == num_vectors * dimension."""
+        flat = _f32(data).reshape(-1)
+        if flat.size != num_vectors * dimension:
+            raise InnrPanic(f"assertion failed: data.len() == num_vectors * dimension ({flat.size} vs "
+                            f"{num_vectors * dimension})")
+        return cls._upload("innr_batch_upload_rowmajor", flat, num_vectors, dimension, ctx)
+
+    @classmethod
+    def from_data(cls, data, num_vectors: int, dimension: int, ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """Inverse of data(): adopt an already dimension-major buffer (VerticalBatch::data(), batch.rs:212)."""
+        col = _f32(data).reshape(-1)
+        if col.size != num_vectors * dimension:
+            raise InnrPanic("data.len() != num_vectors * dimension")
+        return cls._upload("innr_batch_upload_colmajor", col, num_vectors, dimension, ctx)
+
+    @classmethod
+    def generate(cls, num_vectors: int, dimension: int, seed0: int = 0,
+                 ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """Synthetic corpus made on the device: row i = generate_embedding(dimension, seed0 + i)
+        (examples/batch_demo.rs:167, 233-242)."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(load().innr_batch_generate(ctx.handle, num_vectors, dimension, C.c_uint64(seed0), C.byref(h)))
+        return cls(h, num_vectors, dimension, ctx)
+
+    # ---- accessors (batch.rs:187-219) --------------------------------------------------------------
+    def num_vectors(self) -> int:
+        return self._n
+
+    def dimension(self) -> int:
+        return self._d
+
+    def data(self) -> np.ndarray:
+        """Raw data in dimension-major order, shape (dimension, num_vectors) viewable as flat [d*N+i]."""
+        if self._host is None:
+            out = np.empty((self._d, self._n), dtype=np.float32)
+            check(load().innr_batch_download_colmajor(self._h, _vp(out) if out.size else None))
+            self._host = out
+        return self._host
+
+    def get(self, dim: int, vec_idx: int) -> float:
+        return float(self.data()[dim, vec_idx])
+
+    def dimension_slice(self, dim: int) -> np.ndarray:
+        return self.data()[dim]
+
+    def extract_vector(self, vec_idx: int) -> np.ndarray:
+        return self.data()[:, vec_idx].copy()
+
+    def set_index_base(self, base: int) -> None:
+        """Range-partitioned corpus: indices reported by kNN become base + local index."""
+        check(load().innr_batch_set_index_base(self._h, C.c_uint64(base)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            load().innr_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class BatchKnnResult:
+    """batch.rs:368-377: indices and scores, best first."""
+    indices: List[int] = field(default_factory=list)
+    scores: List[float] = field(default_factory=list)
+
+    def __eq__(self, other):
+        return (isinstance(other, BatchKnnResult) and list(self.indices) == list(other.indices)
+                and np.array_equal(np.asarray(self.scores, np.float32), np.asarray(other.scores, np.float32)))
+
+
+def _assert_dim(query: np.ndarray, batch: VerticalBatch) -> None:
+    if query.size != batch.dimension():  # assert_eq!(query.len(), batch.dimension)
+        raise InnrPanic(f"assertion `left == right` failed\n  left: {query.size}\n right: {batch.dimension()}")
+
+
+def _scores(metric: int, query, batch: VerticalBatch, norms=None) -> np.ndarray:
+    q = _f32(query).reshape(-1)
+    _assert_dim(q, batch)
+    out = np.empty(batch.num_vectors(), dtype=np.float32)
+    nrm = None
+    if norms is not None:
+        nrm = _f32(norms).reshape(-1)
+        if nrm.size != batch.num_vectors():  # assert_eq!(norms.len(), batch.num_vectors) batch.rs:711
+            raise InnrPanic(f"assertion `left == right` failed\n  left: {nrm.size}\n right: {batch.num_vectors()}")
+    check(load().innr_batch_scores(batch._h, metric, _vp(q) if q.size else None, q.size,
+                                   _vp(nrm) if nrm is not None and nrm.size else None,
+                                   _vp(out) if out.size else None))
+    return out
+
+
+def _refill(dst: list, values: np.ndarray) -> None:
+    dst.clear()            # Vec::clear + resize: the caller's allocation is reused
+    dst.extend(values.tolist())
+
+
+def batch_l2_squared(query, batch: VerticalBatch) -> np.ndarray:
+    """batch.rs:236-240."""
+    return _scores(METRIC_L2SQ, query, batch)
+
+
+def batch_l2_squared_into(query, batch: VerticalBatch, distances: list) -> None:
+    """batch.rs:250-266."""
+    _refill(distances, _scores(METRIC_L2SQ, query, batch))
+
+
+def batch_dot(query, batch: VerticalBatch) -> np.ndarray:
+    """batch.rs:270-274."""
+    return _scores(METRIC_DOT, query, batch)
+
+
+def batch_dot_into(query, batch: VerticalBatch, products: list) -> None:
+    """batch.rs:284-297."""
+    _refill(products, _scores(METRIC_DOT, query, batch))
+
+
+def batch_norms(batch: VerticalBatch) -> np.ndarray:
+    """batch.rs:663-667."""
+    out = np.empty(batch.num_vectors(), dtype=np.float32)
+    check(load().innr_batch_norms(batch._h, _vp(out) if out.size else None))
+    return out
+
+
+def batch_norms_into(batch: VerticalBatch, norms: list) -> None:
+    """batch.rs:672-686."""
+    _refill(norms, batch_norms(batch))
+
+
+def batch_cosine(query, batch: VerticalBatch, norms) -> np.ndarray:
+    """batch.rs:690-694."""
+    if len(norms) != batch.num_vectors():
+        raise InnrPanic(f"assertion `left == right` failed\n  left: {len(norms)}\n right: {batch.num_vectors()}")
+    return _scores(METRIC_COSINE, query, batch, norms if batch.num_vectors() else None)
+
+
+def batch_cosine_into(query, batch: VerticalBatch, norms, cosines: list) -> None:
+    """batch.rs:705-728."""
+    _refill(cosines, batch_cosine(query, batch, norms))
+
+
+# ---- kNN ---------------------------------------------------------------------------------------------
+def knn_multi(metric: int, queries, batch: VerticalBatch, k: int, engine: int = KNN_AUTO,
+              stats: Optional[KnnStats] = None):
+    """Q queries at once. Returns (indices uint64 [Q, k'], scores float32 [Q, k'])."""
+    q = _f32(queries)
+    if q.ndim == 1:
+        q = q.reshape(1, -1)
+    nq, d = q.shape
+    if d != batch.dimension():
+        raise InnrPanic(f"assertion `left == right` failed\n  left: {d}\n right: {batch.dimension()}")
+    kk = min(int(k), batch.num_vectors())
+    idx = np.empty((nq, max(kk, 1)), dtype=np.uint64)
+    sc = np.empty((nq, max(kk, 1)), dtype=np.float32)
+    out_k = C.c_size_t(0)
+    st = stats if stats is not None else KnnStats()
+    check(load().innr_batch_knn(batch._h, metric, _vp(q) if q.size else None, nq, d, int(k), engine, _vp(idx),
+                                _vp(sc), C.byref(out_k), C.byref(st)))
+    r = int(out_k.value)
+    return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
+
+
+def _knn_single(metric: int, query, batch: VerticalBatch, k: int, engine: int) -> BatchKnnResult:
+    q = _f32(query).reshape(-1)
+    _assert_dim(q, batch)
+    idx, sc = knn_multi(metric, q.reshape(1, -1), batch, k, engine)
+    return BatchKnnResult(indices=[int(i) for i in idx[0]], scores=[float(s) for s in sc[0]])
+
+
+def batch_knn(query, batch: VerticalBatch, k: int, engine: int = KNN_AUTO) -> BatchKnnResult:
+    """batch.rs:385-411: k nearest by squared L2, ascending."""
+    return _knn_single(METRIC_L2SQ, query, batch, k, engine)
+
+
+def batch_knn_dot(query, batch: VerticalBatch, k: int, engine: int = KNN_AUTO) -> BatchKnnResult:
+    """batch.rs:742-764: k highest dot products, descending."""
+    return _knn_single(METRIC_DOT, query, batch, k, engine)
+
+
+def batch_knn_cosine(query, batch: VerticalBatch, k: int, engine: int = KNN_AUTO) -> BatchKnnResult:
+    """batch.rs:777-800: k highest cosine similarities, descending."""
+    return _knn_single(METRIC_COSINE, query, batch, k, engine)
+
+
+def batch_knn_dot_multi(queries, batch: VerticalBatch, k: int, engine: int = KNN_AUTO, stats=None):
+    return knn_multi(METRIC_DOT, queries, batch, k, engine, stats)
+
+
+def batch_knn_cosine_multi(queries, batch: VerticalBatch, k: int, engine: int = KNN_AUTO, stats=None):
+    return knn_multi(METRIC_COSINE, queries, batch, k, engine, stats)
+
+
+def batch_knn_multi(queries, batch: VerticalBatch, k: int, engine: int = KNN_AUTO, stats=None):
+    return knn_multi(METRIC_L2SQ, queries, batch, k, engine, stats)
+
+
+def _not_yet(name: str, where: str):
+    def f(*a, **kw):
+        raise NotImplementedError(f"{name} ({where}) has no device kernel yet in innr_amd; there is no CPU "
+                                  "fallback by design (SURVEY.md 8f 'next')")
+    f.__name__ = name
+    return f
+
+
+batch_knn_filtered: Callable = _not_yet("batch_knn_filtered", "batch.rs:820-882")
+batch_knn_reordered: Callable = _not_yet("batch_knn_reordered", "batch.rs:621-659")
+batch_l2_squared_pruning: Callable = _not_yet("batch_l2_squared_pruning", "batch.rs:320-365")

@@ -1,0 +1,617 @@
+// api.hip -- the extern "C" boundary (include/innr_hip.h) over the gfx950 kernels.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "kernels_prep.h"
+#include "kernels_scan.h"
+#include "kernels_topk.h"
+#include "kernels_gemm.h"
+
+namespace innr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// A device buffer that only grows (workspace; never reallocated inside a steady-state call).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    innr_status ensure(size_t need) {
+        if (need <= bytes) return INNR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        INNR_HIP_CHECK(hipMalloc(&p, need));
+        bytes = need;
+        return INNR_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace innr
+
+using namespace innr;
+
+struct innr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // workspace
+    DevBuf q_row;     // queries row-major [Q][ldq]
+    DevBuf q_kmajor;  // queries K-major [Dpad][Qpad] for the GEMM engine
+    DevBuf q_norm;    // [Q] exact query norms
+    DevBuf lists;     // candidate lists
+    DevBuf counts;    // list counts
+    DevBuf sel;       // selected composites [Q][KP]
+    DevBuf sel_cnt;   // [Q]
+    DevBuf scores;    // [QB][ldN] materialised scores
+    DevBuf tmp_norms; // caller-provided norms staged on device
+    DevBuf flags;     // error flag + per-query fallback flags
+    DevBuf out_idx;   // staging for host-pointer entry points
+    DevBuf out_score;
+    DevBuf misc;
+};
+
+struct innr_batch {
+    innr_ctx* ctx = nullptr;
+    size_t N = 0, D = 0, ldN = 0, Dpad = 0;
+    float* V = nullptr;      // [Dpad][ldN]
+    float* norms = nullptr;  // [ldN], lazily computed (exact batch_norms)
+    uint32_t* max_norm_bits = nullptr;
+    bool norms_ready = false;
+    float max_norm = 0.0f;
+    uint64_t index_base = 0;
+};
+
+namespace innr {
+
+static innr_status bind_device(innr_ctx* ctx) {
+    INNR_HIP_CHECK(hipSetDevice(ctx->device));
+    return INNR_OK;
+}
+
+static innr_status alloc_batch(innr_ctx* ctx, size_t N, size_t D, innr_batch** out) {
+    if (!ctx || !out) {
+        set_error("null ctx/out");
+        return INNR_E_BAD_ARG;
+    }
+    if (N >= 0xFFFFFFFFull - 256 || D > 0x7FFFFFFFull) {
+        set_error("corpus shard too large for u32 device indices (N=%zu, D=%zu)", N, D);
+        return INNR_E_UNSUPPORTED;
+    }
+    INNR_TRY(bind_device(ctx));
+    innr_batch* b = new (std::nothrow) innr_batch();
+    if (!b) return INNR_E_OOM;
+    b->ctx = ctx;
+    b->N = N;
+    b->D = D;
+    b->ldN = round_up(N ? N : 1, 256);
+    b->Dpad = round_up(D ? D : 1, 32);
+    const size_t bytes = b->ldN * b->Dpad * sizeof(float);
+    hipError_t e = hipMalloc((void**)&b->V, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for corpus failed: %s", bytes, hipGetErrorString(e));
+        delete b;
+        return INNR_E_OOM;
+    }
+    e = hipMemsetAsync(b->V, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+        (void)hipFree(b->V);
+        delete b;
+        return INNR_E_HIP;
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+static innr_status ensure_norms(innr_batch* b) {
+    if (b->norms_ready) return INNR_OK;
+    innr_ctx* ctx = b->ctx;
+    if (!b->norms) {
+        INNR_HIP_CHECK(hipMalloc((void**)&b->norms, b->ldN * sizeof(float)));
+        INNR_HIP_CHECK(hipMalloc((void**)&b->max_norm_bits, sizeof(uint32_t)));
+    }
+    INNR_HIP_CHECK(hipMemsetAsync(b->max_norm_bits, 0, sizeof(uint32_t), ctx->stream));
+    const unsigned blocks = (unsigned)((b->ldN / 4 + 255) / 256);
+    norms_kernel<<<blocks, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, b->norms,
+                                                   b->max_norm_bits);
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t bits = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&bits, b->max_norm_bits, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(&b->max_norm, &bits, 4);
+    b->norms_ready = true;
+    return INNR_OK;
+}
+
+static bool metric_ok(int m) { return m == INNR_METRIC_DOT || m == INNR_METRIC_L2SQ || m == INNR_METRIC_COSINE; }
+
+static uint32_t pick_kp(size_t k, size_t margin) {
+    uint32_t kp = 32;
+    while (kp < k + margin) kp <<= 1;
+    return kp;
+}
+
+// ---- exact engine ---------------------------------------------------------------------------------
+template <int QB>
+static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
+                                      uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps) {
+    innr_ctx* c = b->ctx;
+    uint64_t* lists = c->lists.as<uint64_t>();
+    uint32_t* counts = c->counts.as<uint32_t>();
+    uint32_t* err = c->flags.as<uint32_t>();
+    const uint32_t N = (uint32_t)b->N, D = (uint32_t)b->D;
+    switch (metric) {
+        case INNR_METRIC_DOT:
+            scan_filter_kernel<QB, false, false><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cap, cps, err);
+            break;
+        case INNR_METRIC_L2SQ:
+            scan_filter_kernel<QB, true, false><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cap, cps, err);
+            break;
+        default:
+            scan_filter_kernel<QB, false, true><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cap, cps, err);
+            break;
+    }
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// Exact kNN for queries [q0, q0+nq) (row-major on device, stride ldq): results to d_out_* at row q0.
+static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
+                                   size_t q0, size_t nq, size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+    innr_ctx* c = b->ctx;
+    const uint32_t KP = pick_kp(kout, 0);
+    const uint32_t cap = (uint32_t)cand_cap((int)KP);
+    const size_t nchunks = b->ldN / kScanChunk;
+    // wave slots: enough to fill the chip (8 waves / CU) but never more than there are chunks
+    size_t nslots = std::min<size_t>(nchunks, (size_t)c->num_cus * 8);
+    nslots = round_up(nslots, kScanThreads / 64);
+    const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
+    const uint32_t nblocks = (uint32_t)(nslots / (kScanThreads / 64));
+    constexpr uint32_t QBMAX = 8;
+    INNR_TRY(c->lists.ensure(nslots * QBMAX * cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure(nslots * QBMAX * sizeof(uint32_t)));
+    INNR_TRY(c->sel.ensure(QBMAX * KP * sizeof(uint64_t)));
+    INNR_TRY(c->sel_cnt.ensure(QBMAX * sizeof(uint32_t)));
+    const bool l2 = metric == INNR_METRIC_L2SQ;
+    size_t done = 0;
+    while (done < nq) {
+        const size_t rem = nq - done;
+        const uint32_t qb = rem >= 8 ? 8 : (rem >= 4 ? 4 : (rem >= 2 ? 2 : 1));
+        const float* q = dQ + (q0 + done) * ldq;
+        const float* qn = dQn ? dQn + q0 + done : nullptr;
+        switch (qb) {
+            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
+            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
+            case 2: INNR_TRY(launch_scan_filter<2>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
+            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
+        }
+        select_topk_kernel<<<qb, kSelThreads, 0, c->stream>>>(c->lists.as<uint64_t>(), c->counts.as<uint32_t>(),
+                                                              (uint32_t)nslots, qb, cap, KP, c->sel.as<uint64_t>(),
+                                                              c->sel_cnt.as<uint32_t>());
+        INNR_HIP_CHECK(hipGetLastError());
+        const uint32_t total = qb * (uint32_t)kout;
+        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
+            c->sel.as<uint64_t>(), KP, qb, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
+            d_out_score + (q0 + done) * kout);
+        INNR_HIP_CHECK(hipGetLastError());
+        done += qb;
+    }
+    return INNR_OK;
+}
+
+// GEMM engine host driver (defined once the kernel exists)
+static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* dQn,
+                            uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
+                            float* gemm_ms) {
+    set_error("MFMA engine not built yet");
+    return INNR_E_UNSUPPORTED;
+}
+
+static innr_status check_errflag(innr_ctx* c) {
+    uint32_t e = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&e, c->flags.p, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (e) {
+        set_error("internal: candidate-list invariant violated (flag=%u)", e);
+        return INNR_E_HIP;
+    }
+    return INNR_OK;
+}
+
+}  // namespace innr
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* innr_last_error(void) { return g_err; }
+const char* innr_version(void) { return "innr-hip 0.1.0 (gfx950)"; }
+
+innr_status innr_ctx_create(int device, innr_ctx** out) {
+    if (!out) {
+        set_error("out is null");
+        return INNR_E_BAD_ARG;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s): this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return INNR_E_HIP;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range [0,%d)", device, count);
+        return INNR_E_BAD_ARG;
+    }
+    INNR_HIP_CHECK(hipSetDevice(device));
+    innr_ctx* c = new (std::nothrow) innr_ctx();
+    if (!c) return INNR_E_OOM;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        delete c;
+        return INNR_E_HIP;
+    }
+    c->own_stream = true;
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    innr_status s = c->flags.ensure(4096);
+    if (s != INNR_OK) {
+        innr_ctx_destroy(c);
+        return s;
+    }
+    (void)hipMemsetAsync(c->flags.p, 0, 4096, c->stream);
+    *out = c;
+    return INNR_OK;
+}
+
+void innr_ctx_destroy(innr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
+    if (!c) return INNR_E_BAD_ARG;
+    INNR_TRY(bind_device(c));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        INNR_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return INNR_OK;
+}
+
+innr_status innr_ctx_synchronize(innr_ctx* c) {
+    if (!c) return INNR_E_BAD_ARG;
+    INNR_TRY(bind_device(c));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return INNR_OK;
+}
+
+// ---- VerticalBatch -----------------------------------------------------------------------------------
+innr_status innr_batch_upload_colmajor(innr_ctx* ctx, const float* data, size_t N, size_t D, innr_batch** out) {
+    if (!data && N * D) {
+        set_error("data is null");
+        return INNR_E_BAD_ARG;
+    }
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch(ctx, N, D, &b));
+    if (N && D) {
+        hipError_t e = hipMemcpy2DAsync(b->V, b->ldN * sizeof(float), data, N * sizeof(float), N * sizeof(float), D,
+                                        hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("corpus upload failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t N, size_t D, innr_batch** out) {
+    if (!rows && N * D) {
+        set_error("rows is null");
+        return INNR_E_BAD_ARG;
+    }
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch(ctx, N, D, &b));
+    if (N && D) {
+        // stage row blocks (<= 256 MiB) and transpose them into place on the device
+        const size_t max_rows = std::max<size_t>(1, (256ull << 20) / (D * sizeof(float)));
+        const size_t blk = std::min(N, max_rows);
+        float* stage = nullptr;
+        hipError_t e = hipMalloc((void**)&stage, blk * D * sizeof(float));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(stage) failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_OOM;
+        }
+        for (size_t i0 = 0; i0 < N && e == hipSuccess; i0 += blk) {
+            const size_t n = std::min(blk, N - i0);
+            e = hipMemcpyAsync(stage, rows + i0 * D, n * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) break;
+            dim3 grid((unsigned)((n + 31) / 32), (unsigned)((D + 31) / 32));
+            transpose_rows_kernel<<<grid, 256, 0, ctx->stream>>>(stage, (uint32_t)n, (uint32_t)D, b->V, b->ldN, i0);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipFree(stage);
+        if (e != hipSuccess) {
+            set_error("row-major upload failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, uint64_t seed0, innr_batch** out) {
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch(ctx, N, D, &b));
+    if (N && D) {
+        if (D > 65535) {
+            set_error("innr_batch_generate: D > 65535 unsupported");
+            innr_batch_free(b);
+            return INNR_E_UNSUPPORTED;
+        }
+        dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)D);
+        generate_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)N, (uint32_t)D, seed0);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("generate failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+void innr_batch_free(innr_batch* b) {
+    if (!b) return;
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    if (b->V) (void)hipFree(b->V);
+    if (b->norms) (void)hipFree(b->norms);
+    if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
+    delete b;
+}
+
+size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
+size_t innr_batch_dimension(const innr_batch* b) { return b ? b->D : 0; }
+
+innr_status innr_batch_download_colmajor(innr_batch* b, float* out) {
+    if (!b || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
+    if (b->N == 0 || b->D == 0) return INNR_OK;
+    INNR_TRY(bind_device(b->ctx));
+    INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), b->V, b->ldN * sizeof(float), b->N * sizeof(float),
+                                    b->D, hipMemcpyDeviceToHost, b->ctx->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return INNR_OK;
+}
+
+innr_status innr_batch_set_index_base(innr_batch* b, uint64_t base) {
+    if (!b) return INNR_E_BAD_ARG;
+    b->index_base = base;
+    return INNR_OK;
+}
+
+// ---- scans ---------------------------------------------------------------------------------------------
+innr_status innr_batch_norms(innr_batch* b, float* out) {
+    if (!b || (!out && b->N)) return INNR_E_BAD_ARG;
+    if (b->N == 0) return INNR_OK;
+    INNR_TRY(bind_device(b->ctx));
+    INNR_TRY(ensure_norms(b));
+    INNR_HIP_CHECK(hipMemcpyAsync(out, b->norms, b->N * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return INNR_OK;
+}
+
+innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t D, const float* norms, float* out) {
+    if (!b || !metric_ok(metric)) {
+        set_error("bad batch/metric");
+        return INNR_E_BAD_ARG;
+    }
+    if (D != b->D) {  // assert_eq!(query.len(), batch.dimension) batch.rs:251,285
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    if (b->N == 0) return INNR_OK;
+    if (!out || (!q && D)) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const size_t ldq = round_up(D ? D : 1, 4);
+    INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(sizeof(float)));
+    INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const float* dn = nullptr;
+    if (metric == INNR_METRIC_COSINE) {
+        if (norms) {  // the reference signature passes the caller's norms (batch.rs:690)
+            INNR_TRY(c->tmp_norms.ensure(b->ldN * sizeof(float)));
+            INNR_HIP_CHECK(hipMemsetAsync(c->tmp_norms.p, 0, b->ldN * sizeof(float), c->stream));
+            INNR_HIP_CHECK(hipMemcpyAsync(c->tmp_norms.p, norms, b->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            dn = c->tmp_norms.as<float>();
+        } else {
+            INNR_TRY(ensure_norms(b));
+            dn = b->norms;
+        }
+        query_norms_kernel<<<1, 64, 0, c->stream>>>(c->q_row.as<float>(), 1, (uint32_t)D, ldq, c->q_norm.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    const size_t nchunks = b->ldN / kScanChunk;
+    const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+    const float* dq = c->q_row.as<float>();
+    float* ds = c->scores.as<float>();
+    switch (metric) {
+        case INNR_METRIC_DOT:
+            scan_scores_kernel<1, false, false><<<blocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, (uint32_t)D, dq, ldq, nullptr, nullptr, ds, b->ldN);
+            break;
+        case INNR_METRIC_L2SQ:
+            scan_scores_kernel<1, true, false><<<blocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, (uint32_t)D, dq, ldq, nullptr, nullptr, ds, b->ldN);
+            break;
+        default:
+            scan_scores_kernel<1, false, true><<<blocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, (uint32_t)D, dq, ldq, dn, c->q_norm.as<float>(), ds, b->ldN);
+            break;
+    }
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipMemcpyAsync(out, ds, b->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return INNR_OK;
+}
+
+// ---- kNN -----------------------------------------------------------------------------------------------
+innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D, size_t k,
+                               int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
+                               innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!b || !metric_ok(metric) || !out_k) {
+        set_error("bad batch/metric/out_k");
+        return INNR_E_BAD_ARG;
+    }
+    if (D != b->D) {  // batch.rs:386,743,778
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    *out_k = 0;
+    if (b->N == 0 || k == 0 || Q == 0) return INNR_OK;  // batch.rs:388-393, 745-750
+    const size_t kout = std::min(k, b->N);              // batch.rs:395, 752
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && metric != INNR_METRIC_L2SQ) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    if (engine == INNR_KNN_MFMA && metric == INNR_METRIC_L2SQ) {
+        set_error("MFMA engine does not implement L2SQ yet; use INNR_KNN_EXACT/AUTO");
+        return INNR_E_UNSUPPORTED;
+    }
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    const float* dQn = nullptr;
+    if (metric == INNR_METRIC_COSINE) {
+        INNR_TRY(ensure_norms(b));
+        INNR_TRY(c->q_norm.ensure(Q * sizeof(float)));
+        query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+                                                                           c->q_norm.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+        dQn = c->q_norm.as<float>();
+    }
+    uint32_t nfallback = 0, kept = 0;
+    float gemm_ms = 0.0f;
+    if (engine == INNR_KNN_MFMA) {
+        INNR_TRY(knn_mfma(b, metric, d_queries, Q, kout, dQn, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
+    } else {
+        INNR_TRY(knn_exact_range(b, metric, d_queries, D, dQn, 0, Q, kout, d_out_idx, d_out_score));
+        kept = pick_kp(kout, 0);
+    }
+    INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    INNR_TRY(check_errflag(c));
+    *out_k = kout;
+    if (stats) {
+        stats->engine = engine;
+        stats->queries_fallback = nfallback;
+        stats->candidates_kept = kept;
+        stats->gemm_ms = gemm_ms;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
+    }
+    return INNR_OK;
+}
+
+innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, size_t k, int engine,
+                           uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!b || !out_k) return INNR_E_BAD_ARG;
+    if (D != b->D) {
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    *out_k = 0;
+    if (b->N == 0 || k == 0 || Q == 0) return INNR_OK;
+    if (!queries && D) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const size_t kout = std::min(k, b->N);
+    INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
+    INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_TRY(innr_batch_knn_dev(b, metric, c->q_row.as<float>(), Q, D, k, engine, c->out_idx.as<uint64_t>(),
+                                c->out_score.as<float>(), out_k, stats));
+    if (*out_k) {
+        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return INNR_OK;
+}
+
+innr_status innr_merge_topk_dev(innr_ctx* ctx, int metric, const uint64_t* d_idx, const float* d_score, size_t G,
+                                size_t Q, size_t kin, size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+    if (!ctx || !metric_ok(metric) || !d_idx || !d_score || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
+    if (Q == 0 || kout == 0) return INNR_OK;
+    if (kout > G * kin) {
+        set_error("merge: kout=%zu > G*kin=%zu", kout, G * kin);
+        return INNR_E_BAD_ARG;
+    }
+    INNR_TRY(bind_device(ctx));
+    merge_topk_kernel<<<(unsigned)Q, 64, 0, ctx->stream>>>(d_idx, d_score, (uint32_t)G, (uint32_t)Q, (uint32_t)kin,
+                                                          (uint32_t)kout, metric == INNR_METRIC_L2SQ, d_out_idx,
+                                                          d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return INNR_OK;
+}
+
+}  // extern "C"

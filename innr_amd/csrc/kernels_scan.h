@@ -1,0 +1,161 @@
+// kernels_scan.h -- the bit-exact scan: batch_dot_into / batch_l2_squared_into / batch_cosine_into
+// (src/batch.rs:284-297, 250-266, 705-728) for up to QB queries per corpus pass.
+//
+// HBM-bound design (roofline: 4*N*D bytes per pass): one lane owns 4 consecutive corpus
+// vectors and keeps their QB accumulators in registers; a wave reads each dimension row as one coalesced
+// 1 KiB float4 access (the PDX layout makes lane i's element of row d contiguous with lane i+1's).
+// Each lane walks d = 0..D-1 in the reference's order with fl(acc + fl(q*v)) (ex::mad2), so outputs are
+// bit-identical to the Rust loops -- which also means the reference's N-long accumulator array that is
+// re-streamed D times on the CPU (8*N*D bytes of extra traffic) never exists here.
+#pragma once
+
+#include "common.h"
+#include "topk_dev.h"
+
+namespace innr {
+
+constexpr int kScanThreads = 256;          // 4 waves
+constexpr int kScanChunk = 64 * 4;         // vectors per wave step (64 lanes x float4)
+
+// acc[j][c] for QB queries x 4 vectors starting at column `col` (col % 4 == 0, col + 3 < ldN).
+template <int QB, bool L2>
+__device__ __forceinline__ void scan_accumulate(const float* __restrict__ V, size_t ldN, uint32_t D, size_t col,
+                                                const float* __restrict__ Qm, size_t ldq, float (&acc)[QB][4]) {
+#pragma unroll
+    for (int j = 0; j < QB; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
+    const float4* p = reinterpret_cast<const float4*>(V + col);
+    const size_t stride = ldN / 4;
+#pragma unroll 8
+    for (uint32_t d = 0; d < D; ++d) {
+        const float4 v = p[(size_t)d * stride];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const float q = Qm[(size_t)j * ldq + d];  // wave-uniform -> scalar load
+            if (L2) {  // batch.rs:262-263: diff = q_d - v_d; dist += diff*diff
+                const float d0 = ex::sub(q, v.x), d1 = ex::sub(q, v.y), d2 = ex::sub(q, v.z), d3 = ex::sub(q, v.w);
+                acc[j][0] = ex::mad2(acc[j][0], d0, d0);
+                acc[j][1] = ex::mad2(acc[j][1], d1, d1);
+                acc[j][2] = ex::mad2(acc[j][2], d2, d2);
+                acc[j][3] = ex::mad2(acc[j][3], d3, d3);
+            } else {  // batch.rs:294: prod += q_d * v_d
+                acc[j][0] = ex::mad2(acc[j][0], q, v.x);
+                acc[j][1] = ex::mad2(acc[j][1], q, v.y);
+                acc[j][2] = ex::mad2(acc[j][2], q, v.z);
+                acc[j][3] = ex::mad2(acc[j][3], q, v.w);
+            }
+        }
+    }
+}
+
+// batch.rs:716-727 epilogue for one value: whole output 0 if ||q|| < eps; 0 if ||v|| <= eps
+__device__ __forceinline__ float cosine_epilogue(float dot, float qn, float vn) {
+    if (qn < INNR_NORM_EPSILON) return 0.0f;
+    return (vn > INNR_NORM_EPSILON) ? ex::div(dot, ex::mul(qn, vn)) : 0.0f;
+}
+
+// ---- materialising variant: out[j*ldo + i] for all i (innr_batch_scores) -----------------------------
+template <int QB, bool L2, bool COS>
+__global__ __launch_bounds__(kScanThreads) void scan_scores_kernel(const float* __restrict__ V, size_t ldN,
+                                                                    uint32_t D, const float* __restrict__ Qm,
+                                                                    size_t ldq, const float* __restrict__ norms,
+                                                                    const float* __restrict__ qnorm,
+                                                                    float* __restrict__ out, size_t ldo) {
+    const size_t nchunks = ldN / kScanChunk;
+    const size_t wave = ((size_t)blockIdx.x * kScanThreads + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * kScanThreads) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (size_t ch = wave; ch < nchunks; ch += nwaves) {
+        const size_t col = ch * kScanChunk + (size_t)lane * 4;
+        float acc[QB][4];
+        scan_accumulate<QB, L2>(V, ldN, D, col, Qm, ldq, acc);
+        float4 vn = make_float4(0, 0, 0, 0);
+        if (COS) vn = *reinterpret_cast<const float4*>(norms + col);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            float4 o = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            if (COS) {
+                const float qn = qnorm[j];
+                o.x = cosine_epilogue(o.x, qn, vn.x);
+                o.y = cosine_epilogue(o.y, qn, vn.y);
+                o.z = cosine_epilogue(o.z, qn, vn.z);
+                o.w = cosine_epilogue(o.w, qn, vn.w);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)j * ldo + col) = o;
+        }
+    }
+}
+
+// ---- fused top-k variant: exact scores -> threshold filter -> per-wave candidate lists ---------------
+// Wave `slot` owns chunks [slot*cps, (slot+1)*cps) and lists[slot][0..QB). See topk_dev.h.
+template <int QB, bool L2, bool COS>
+__global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
+    const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, const float* __restrict__ Qm, size_t ldq,
+    const float* __restrict__ norms, const float* __restrict__ qnorm, uint64_t* __restrict__ lists,
+    uint32_t* __restrict__ counts, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t chunks_per_slot,
+    uint32_t* __restrict__ errflag) {
+    __shared__ uint32_t s_cnt[kScanThreads / 64][QB];
+    __shared__ uint32_t s_thr[kScanThreads / 64][QB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t slot = (size_t)blockIdx.x * (kScanThreads / 64) + w;
+    if (lane < QB) {
+        s_cnt[w][lane] = 0;
+        s_thr[w][lane] = 0;  // pref 0 = no threshold: everything is admitted
+    }
+    __builtin_amdgcn_wave_barrier();
+    const size_t nchunks = ldN / kScanChunk;
+    size_t ch0 = slot * chunks_per_slot, ch1 = ch0 + chunks_per_slot;
+    if (ch1 > nchunks) ch1 = nchunks;
+    uint64_t* my_lists = lists + slot * (size_t)qstride * cap;
+    for (size_t ch = ch0; ch < ch1; ++ch) {
+        const size_t col = ch * kScanChunk + (size_t)lane * 4;
+        float acc[QB][4];
+        scan_accumulate<QB, L2>(V, ldN, D, col, Qm, ldq, acc);
+        float vn[4] = {0, 0, 0, 0};
+        if (COS) {
+            const float4 t = *reinterpret_cast<const float4*>(norms + col);
+            vn[0] = t.x; vn[1] = t.y; vn[2] = t.z; vn[3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const uint32_t thr = __hip_atomic_load(&s_thr[w][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const float qn = COS ? qnorm[j] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const size_t i = col + c;
+                float s = acc[j][c];
+                if (COS) s = cosine_epilogue(s, qn, vn[c]);
+                const uint32_t pref = score_pref<L2>(s);
+                if (i < N && pref >= thr)
+                    cand_append(my_lists + (size_t)j * cap, &s_cnt[w][j], cap, cand_make(pref, (uint32_t)i), errflag);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const uint32_t c = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(&s_cnt[w][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+            if (c > cap - kBurst) {  // wave-uniform (scalar branch)
+                uint32_t t;
+                const uint32_t keep = wave_compact_dyn(my_lists + (size_t)j * cap, c, KP, cap, &t);
+                if (lane == 0) {
+                    s_cnt[w][j] = keep;
+                    s_thr[w][j] = t;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // leave at most KP entries per list (bounds the select kernel's work), then publish the counts
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        uint32_t c = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&s_cnt[w][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+        if (c > KP) {
+            uint32_t t;
+            c = wave_compact_dyn(my_lists + (size_t)j * cap, c, KP, cap, &t);
+        }
+        if (lane == 0) counts[slot * qstride + j] = c;
+    }
+}
+
+}  // namespace innr

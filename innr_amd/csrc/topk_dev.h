@@ -1,0 +1,98 @@
+// topk_dev.h -- wave-level candidate lists: threshold filter + append + rank-compaction.
+//
+// Replaces, on the device, the reference's "materialise N scores, stable-sort all of them, truncate(k)"
+// (src/batch.rs:756-758, 792-794) and its streaming TopK (src/topk.rs:96-121): a producer wave keeps,
+// per query, a list of 64-bit composites [pref | ~idx] (common.h) in global scratch, admits a score only
+// if it is not worse than the list's threshold (the KP-th best it has proven to exist), and compacts the
+// list to its best KP entries when it runs short of room. Anything rejected or dropped is strictly worse
+// than KP other entries of the same query in (score, index) order, so it can never be in the top KP --
+// the final select kernel therefore reproduces the stable-sort result exactly.
+//
+// All functions are wave-collective: every lane of the wave must reach them (wave-uniform control flow).
+#pragma once
+
+#include "common.h"
+
+namespace innr {
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, lane);
+    uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+// L1-bypassing 8-byte load (agent scope): the list was written by this wave's own earlier stores.
+__device__ __forceinline__ uint64_t load_entry(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Append one candidate. `cnt` lives in LDS and is private to the owning wave; lanes of that wave may
+// append concurrently (LDS atomic hands out distinct slots). The compaction invariant keeps pos < cap;
+// the guard turns a broken invariant into a reported error instead of an out-of-bounds store.
+__device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint32_t cap, uint64_t comp,
+                                            uint32_t* errflag) {
+    uint32_t pos = atomicAdd(cnt, 1u);
+    if (pos < cap) list[pos] = comp;
+    else atomicOr(errflag, 1u);
+}
+
+// Compact a list of `cnt` (<= 64*R) distinct composites to its best min(cnt, KP), written back sorted
+// best-first at list[0..keep). Returns keep; *thr_pref = pref of the KP-th best (0 = "no threshold yet"
+// while fewer than KP entries exist). Rank counting: rank(e) = #entries greater than e; entries are
+// distinct (one per corpus index), so ranks are a permutation and rank < keep selects AND orders.
+template <int R>
+__device__ __forceinline__ uint32_t wave_compact(uint64_t* list, uint32_t cnt, uint32_t KP, uint32_t* thr_pref) {
+    const int lane = threadIdx.x & 63;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2
+    uint64_t e[R];
+    uint32_t rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t slot = r * 64 + lane;
+        e[r] = (slot < cnt) ? load_entry(list + slot) : 0ull;
+        rank[r] = 0;
+    }
+#pragma unroll
+    for (int r2 = 0; r2 < R; ++r2) {
+        if ((uint32_t)(r2 * 64) < cnt) {  // wave-uniform
+            const int lim = (cnt - r2 * 64) < 64u ? (int)(cnt - r2 * 64) : 64;
+            for (int l = 0; l < lim; ++l) {
+                const uint64_t b = readlane_u64(e[r2], l);
+#pragma unroll
+                for (int r = 0; r < R; ++r) rank[r] += (b > e[r]) ? 1u : 0u;
+            }
+        }
+    }
+    const uint32_t keep = cnt < KP ? cnt : KP;
+    uint32_t t = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t slot = r * 64 + lane;
+        if (slot < cnt && rank[r] < keep) list[rank[r]] = e[r];
+        if (slot < cnt && rank[r] == KP - 1) t = cand_pref(e[r]);
+    }
+    *thr_pref = wave_max_u32(t);  // exactly one lane/reg holds rank KP-1 when cnt >= KP, else all 0
+    return keep;
+}
+
+// Dispatch on the list capacity (cap = 64*R; cap = cand_cap(KP) for KP in {32,64,128,256}).
+__device__ __forceinline__ uint32_t wave_compact_dyn(uint64_t* list, uint32_t cnt, uint32_t KP, uint32_t cap,
+                                                     uint32_t* thr_pref) {
+    switch (cap) {
+        case 384: return wave_compact<6>(list, cnt, KP, thr_pref);
+        case 512: return wave_compact<8>(list, cnt, KP, thr_pref);
+        case 768: return wave_compact<12>(list, cnt, KP, thr_pref);
+        default: return wave_compact<20>(list, cnt, KP, thr_pref);  // 1280
+    }
+}
+
+}  // namespace innr

@@ -49,13 +49,22 @@ class OracleBackend:
 class HipBackend:
     name = "hip"
 
-    def __init__(self):
+    def __init__(self, engine=None):
         import innr_amd
-        from innr_amd import batch, maxsim as ms, scalar
+        from innr_amd import batch
         self.m = innr_amd
         self.batch = batch
-        self.ms = ms
-        self.scalar = scalar
+        self.engine = innr_amd.KNN_AUTO if engine is None else engine
+
+    @property
+    def ms(self):
+        from innr_amd import maxsim
+        return maxsim
+
+    @property
+    def scalar(self):
+        from innr_amd import scalar
+        return scalar
 
     def from_rows(self, rows):
         rows = [np.asarray(r, dtype=np.float32) for r in rows]
@@ -73,8 +82,8 @@ class HipBackend:
         return np.asarray(res.indices, dtype=np.uint64), np.asarray(res.scores, dtype=np.float32)
 
     def batch_knn(self, q, b, k): return self._r(self.batch.batch_knn(q, b, k))
-    def batch_knn_dot(self, q, b, k): return self._r(self.batch.batch_knn_dot(q, b, k))
-    def batch_knn_cosine(self, q, b, k): return self._r(self.batch.batch_knn_cosine(q, b, k))
+    def batch_knn_dot(self, q, b, k): return self._r(self.batch.batch_knn_dot(q, b, k, engine=self.engine))
+    def batch_knn_cosine(self, q, b, k): return self._r(self.batch.batch_knn_cosine(q, b, k, engine=self.engine))
     def batch_knn_filtered(self, q, b, k, pred): return self._r(self.batch.batch_knn_filtered(q, b, k, pred))
     def batch_knn_reordered(self, q, b, k): return self._r(self.batch.batch_knn_reordered(q, b, k))
     def batch_l2_squared_pruning(self, q, b, t):

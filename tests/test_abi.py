@@ -1,0 +1,71 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads, and exports exactly the
+symbols include/innr_hip.h declares; the Python binding table matches the header; without a GPU the
+product path fails loudly instead of computing on the CPU."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "innr_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(innr_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from innr_amd import _lib
+    return _lib
+
+
+def test_header_declares_symbols():
+    syms = _declared_symbols()
+    assert "innr_batch_knn" in syms and "innr_ctx_create" in syms and len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/innr_hip.h but not exported"
+
+
+def test_binding_table_matches_header(built):
+    assert sorted(built.SIGNATURES) == _declared_symbols()
+
+
+def test_no_extra_public_symbols(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("innr_")))
+    assert exported == _declared_symbols()
+
+
+def test_code_object_is_gfx950(built):
+    data = open(built.LIB_PATH, "rb").read()
+    assert b"gfx950" in data and b"gfx942" not in data and b"sm_" not in data
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
+def test_fails_loudly_without_gpu(built):
+    from innr_amd import InnrError
+    from innr_amd import batch as B
+    with pytest.raises(InnrError):
+        B.VerticalBatch.from_rows([[1.0, 2.0]])
+    assert "no CPU fallback" in built.last_error() or "HIP" in built.last_error() or "device" in built.last_error()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "innr_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "innr_oracle" not in txt, f

@@ -1,0 +1,253 @@
+"""GPU parity tests, part 1: layout, generator, bit-exact scans and the EXACT kNN engine, all through the
+C ABI (ctypes -> libinnr_hip.so), compared with the CPU oracle on the same seeded inputs.
+Bar: bit-exact scores, identical index lists."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+import kat_cases as K
+from backends import HipBackend
+
+
+@pytest.fixture(scope="module")
+def B():
+    from innr_amd import batch
+    return batch
+
+
+@pytest.fixture(scope="module")
+def innr():
+    import innr_amd
+    return innr_amd
+
+
+def _corpus(n, dim, seed0=0):
+    rows = oracle.generate_corpus(n, dim, seed0)
+    return rows, oracle.from_rows(rows)
+
+
+def _queries(nq, dim, seed0=50_000):
+    return np.stack([oracle.generate_embedding(dim, seed0 + j) for j in range(nq)])
+
+
+# ------------------------------------------------------------------------------- reference KATs on the GPU
+@pytest.mark.parametrize("kat", K.BATCH_KATS, ids=lambda f: f.__name__)
+def test_reference_kat_exact_engine(kat, innr):
+    kat(HipBackend(engine=innr.KNN_EXACT))
+
+
+def test_native_library_is_loaded():
+    from innr_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libinnr_hip.so" in maps
+
+
+# ------------------------------------------------------------------------------- layout / ingest
+@pytest.mark.parametrize("n,dim", [(1, 1), (2, 3), (255, 7), (256, 32), (257, 33), (1000, 128), (4099, 100)])
+def test_layout_roundtrip_all_constructors(B, n, dim):
+    rows, data = _corpus(n, dim, 3)
+    for vb in (B.VerticalBatch.from_rows(rows), B.VerticalBatch.from_flat(rows.reshape(-1), n, dim),
+               B.VerticalBatch.from_data(data.reshape(-1), n, dim)):
+        assert vb.num_vectors() == n and vb.dimension() == dim
+        assert np.array_equal(vb.data(), data)
+        assert np.array_equal(vb.extract_vector(n - 1), rows[n - 1])
+        assert vb.get(dim - 1, 0) == rows[0, dim - 1]
+
+
+def test_layout_errors_and_empty(B, innr):
+    with pytest.raises(innr.InnrPanic):
+        B.VerticalBatch.from_rows([[1.0, 2.0], [1.0]])  # batch.rs:120 "Inconsistent vector dimension"
+    with pytest.raises(innr.InnrPanic):
+        B.VerticalBatch.from_flat([1.0, 2.0, 3.0], 2, 2)  # batch.rs:168
+    e = B.VerticalBatch.from_rows([])
+    assert e.num_vectors() == 0 and e.dimension() == 0 and e.data().shape == (0, 0)
+    assert len(B.batch_dot([], e)) == 0 and len(B.batch_norms(e)) == 0
+    vb = B.VerticalBatch.from_rows([[1.0, 2.0]])
+    for fn in (B.batch_dot, B.batch_l2_squared, lambda q, b: B.batch_knn(q, b, 1), lambda q, b: B.batch_knn_dot(q, b, 1),
+               lambda q, b: B.batch_knn_cosine(q, b, 1)):
+        with pytest.raises(innr.InnrPanic):
+            fn([1.0, 2.0, 3.0], vb)  # assert_eq!(query.len(), batch.dimension)
+    with pytest.raises(innr.InnrPanic):
+        B.batch_cosine([1.0, 2.0], vb, [1.0, 2.0])  # norms.len() != num_vectors, batch.rs:711
+
+
+@pytest.mark.parametrize("n,dim,seed0", [(1000, 128, 0), (257, 33, 1 << 40), (5000, 768, 12345)])
+def test_device_generator_bit_exact(B, n, dim, seed0):
+    vb = B.VerticalBatch.generate(n, dim, seed0)
+    assert np.array_equal(vb.data(), oracle.from_rows(oracle.generate_corpus(n, dim, seed0)))
+
+
+# ------------------------------------------------------------------------------- bit-exact scans
+@pytest.mark.parametrize("n,dim", [(1, 1), (3, 2), (255, 16), (257, 31), (1000, 128), (10_000, 128), (4100, 768)])
+def test_scans_bit_exact(B, n, dim):
+    rows, data = _corpus(n, dim, 7)
+    vb = B.VerticalBatch.from_rows(rows)
+    for q in _queries(3, dim, 999):
+        assert np.array_equal(B.batch_dot(q, vb), oracle.batch_dot(q, data))
+        assert np.array_equal(B.batch_l2_squared(q, vb), oracle.batch_l2_squared(q, data))
+        norms = B.batch_norms(vb)
+        assert np.array_equal(norms, oracle.batch_norms(data))
+        assert np.array_equal(B.batch_cosine(q, vb, norms), oracle.batch_cosine(q, data, norms))
+    out = [123.0]
+    B.batch_dot_into(rows[0], vb, out)
+    assert len(out) == n and np.array_equal(np.float32(out), oracle.batch_dot(rows[0], data))
+
+
+def test_scans_special_values(B):
+    rows = np.array([[1.0, 0.0, -2.0], [0.0, 0.0, 0.0], [np.inf, 1.0, 1.0], [np.nan, 1.0, 1.0], [1e-30, 1e-30, 0.0],
+                     [-0.0, -0.0, -0.0], [3e38, 3e38, 3e38]], dtype=np.float32)
+    data = oracle.from_rows(rows)
+    vb = B.VerticalBatch.from_rows(rows)
+    for q in ([1.0, 2.0, 3.0], [0.0, 0.0, 0.0], [1e-10, 0.0, 0.0], [-1.0, np.inf, 0.5]):
+        q = np.float32(q)
+        for got, exp in ((B.batch_dot(q, vb), oracle.batch_dot(q, data)),
+                         (B.batch_l2_squared(q, vb), oracle.batch_l2_squared(q, data)),
+                         (B.batch_cosine(q, vb, B.batch_norms(vb)), oracle.batch_cosine(q, data, oracle.batch_norms(data)))):
+            # A NaN *generated* by an invalid operation (inf*0, inf/inf) has an ISA-defined sign (x86: negative,
+            # CDNA/ARM: positive), so the reference itself differs across hosts there: compare NaN-ness for
+            # those, bits (incl. -0.0) for everything else.
+            gn, en = np.isnan(got), np.isnan(exp)
+            assert np.array_equal(gn, en), (q, got, exp)
+            assert bits_equal(got[~gn], exp[~en]), (q, got, exp)
+    # caller-supplied norms are honoured (reference signature takes them, batch.rs:690)
+    fake = np.float32([1, 2, 3, 4, 5, 6, 7])
+    q = np.float32([1, 2, 3])
+    got, exp = B.batch_cosine(q, vb, fake), oracle.batch_cosine(q, data, fake)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and bits_equal(got[~np.isnan(got)], exp[~np.isnan(exp)])
+
+
+# ------------------------------------------------------------------------------- exact kNN engine
+def bits_equal(a, b) -> bool:
+    """Bitwise equality of two f32 arrays (so -0.0 != +0.0 and NaN == NaN of the same sign/payload)."""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def same_knn(metric, idx, sc, oi, os_) -> bool:
+    """Scores bit-identical; index lists identical. For L2 (`batch_knn`, TopK path) the reference leaves the
+    order AMONG EXACTLY EQUAL distances to core's binary_search (topk.rs:177-185, SURVEY.md hard part 2), so
+    equal-distance groups are compared as sets; everything else is compared position by position."""
+    if not bits_equal(sc, os_):
+        return False
+    idx = [int(i) for i in idx]; oi = [int(i) for i in oi]
+    if metric != "l2":
+        return idx == oi
+    keys = np.asarray(os_, np.float32).view(np.uint32)
+    for kbits in set(keys.tolist()):
+        sel = [p for p in range(len(oi)) if keys[p] == kbits]
+        if sorted(idx[p] for p in sel) != sorted(oi[p] for p in sel):
+            return False
+    return True
+
+
+def _check_knn(B, innr, metric, rows, data, queries, k, engine):
+    fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
+    ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine, "l2": oracle.batch_knn}[metric]
+    vb = rows if hasattr(rows, "num_vectors") else B.VerticalBatch.from_rows(rows)
+    idx, sc = fn(queries, vb, k, engine=engine)
+    assert idx.shape == (len(queries), min(k, data.shape[1]))
+    for j, q in enumerate(queries):
+        oi, os_ = ofn(q, data, k)
+        assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j, idx[j], oi, sc[j], os_)
+    return vb
+
+
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
+def test_knn_exact_c1_shape(B, innr, metric):
+    # BASELINE.json configs[0]: 10K x 128, 100 queries, k = 10 (examples/batch_demo.rs:159-170)
+    rows, data = _corpus(10_000, 128, 0)
+    _check_knn(B, innr, metric, rows, data, _queries(100, 128), 10, innr.KNN_EXACT)
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(1, 4, 1, 1), (5, 3, 2, 10), (255, 16, 3, 7), (257, 33, 5, 32), (1000, 64, 9, 33),
+                                        (3000, 20, 17, 100), (2049, 8, 4, 240)])
+def test_knn_exact_ragged(B, innr, n, dim, nq, k):
+    rows, data = _corpus(n, dim, 77)
+    vb = None
+    for metric in ("dot", "cos", "l2"):
+        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(nq, dim, 4242), k, innr.KNN_EXACT)
+
+
+def test_knn_exact_single_query_api_matches_reference_shape(B, innr):
+    rows, data = _corpus(2000, 48, 5)
+    vb = B.VerticalBatch.from_rows(rows)
+    q = _queries(1, 48)[0]
+    for fn, ofn in ((B.batch_knn_dot, oracle.batch_knn_dot), (B.batch_knn_cosine, oracle.batch_knn_cosine), (B.batch_knn, oracle.batch_knn)):
+        r = fn(q, vb, 10)
+        oi, os_ = ofn(q, data, 10)
+        assert isinstance(r, B.BatchKnnResult) and r.indices == oi.tolist() and np.array_equal(np.float32(r.scores), os_)
+    assert B.batch_knn_dot(q, vb, 0).indices == [] and B.batch_knn(q, vb, 0).scores == []
+
+
+def test_knn_k_limit_is_loud(B, innr):
+    vb = B.VerticalBatch.generate(1000, 8, 0)
+    with pytest.raises(innr.InnrError):
+        B.batch_knn_dot(np.zeros(8, np.float32), vb, 241)
+
+
+def test_knn_ties_resolve_to_lower_index(B, innr):
+    # duplicated vectors: the reference's stable sort keeps the lower index first (batch.rs:757)
+    base = oracle.generate_corpus(50, 16, 9)
+    rows = np.concatenate([base, base, base[::-1]])  # every vector appears three times
+    data = oracle.from_rows(rows)
+    for metric in ("dot", "cos"):
+        _check_knn(B, innr, metric, rows, data, _queries(6, 16, 31), 12, innr.KNN_EXACT)
+    # L2 ties: same SET and same (distance, index) order as the documented device rule
+    vb = B.VerticalBatch.from_rows(rows)
+    q = _queries(1, 16, 31)[0]
+    r = B.batch_knn(q, vb, 12)
+    oi, os_ = oracle.batch_knn(q, data, 12)
+    assert sorted(r.indices) == sorted(oi.tolist()) and np.array_equal(np.float32(r.scores), os_)
+    assert r.indices == [i for _, i in sorted(zip(r.scores, r.indices))]
+    # all-equal scores: zero query -> every dot is 0.0 -> first k indices
+    r = B.batch_knn_dot(np.zeros(16, np.float32), vb, 7)
+    assert r.indices == list(range(7)) and r.scores == [0.0] * 7
+    r = B.batch_knn_cosine(np.zeros(16, np.float32), vb, 7)  # zero-norm query: all cosines 0 (batch.rs:716)
+    assert r.indices == list(range(7)) and r.scores == [0.0] * 7
+
+
+def test_knn_nan_inf_ordering(B, innr):
+    # A NaN *input* propagates with its sign on every ISA: +NaN sorts above +inf under total_cmp, so it comes
+    # FIRST in a descending sort (batch.rs:757) and LAST in the ascending TopK (topk.rs:101).
+    rows = oracle.generate_corpus(600, 8, 1)
+    rows[17, 3] = np.nan
+    rows[300, 0] = np.inf
+    rows[301, 0] = -np.inf
+    data = oracle.from_rows(rows)
+    q = np.float32([1, 1, 1, 1, 1, 1, 1, 1])
+    for metric in ("dot", "l2"):  # cosine would divide inf/inf: generated NaN, sign is ISA-defined (see above)
+        _check_knn(B, innr, metric, rows, data, q.reshape(1, -1), 5, innr.KNN_EXACT)
+    r = B.batch_knn_dot(q, B.VerticalBatch.from_rows(rows), 3)
+    assert r.indices[:2] == [17, 300] and math.isnan(r.scores[0]) and r.scores[1] == math.inf
+    rows[300, 0] = 5.0; rows[301, 0] = -5.0
+    _check_knn(B, innr, "cos", rows, oracle.from_rows(rows), q.reshape(1, -1), 5, innr.KNN_EXACT)
+
+
+def test_knn_monotone_scores_force_many_compactions(B, innr):
+    # scores increase with the index: every vector beats the running threshold, so candidate lists fill and
+    # compact over and over (the worst case of the threshold filter).
+    n = 200_000
+    rows = np.zeros((n, 2), dtype=np.float32)
+    rows[:, 0] = np.arange(n, dtype=np.float32) * np.float32(0.001)
+    rows[:, 1] = 1.0
+    data = oracle.from_rows(rows)
+    q = np.float32([[1.0, 0.5], [-1.0, 0.25], [0.0, 1.0]])
+    for metric, k in (("dot", 10), ("l2", 10), ("dot", 100), ("cos", 33)):
+        _check_knn(B, innr, metric, rows, data, q, k, innr.KNN_EXACT)
+
+
+def test_index_base_offsets_reported_indices(B, innr):
+    rows, data = _corpus(700, 12, 2)
+    vb = B.VerticalBatch.from_rows(rows)
+    vb.set_index_base(1 << 33)
+    q = _queries(1, 12)[0]
+    r = B.batch_knn_dot(q, vb, 4)
+    oi, _ = oracle.batch_knn_dot(q, data, 4)
+    assert r.indices == [int(i) + (1 << 33) for i in oi]

@@ -79,9 +79,16 @@ innr_status innr_batch_upload_colmajor(innr_ctx* ctx, const float* data, size_t 
 /* rows = what from_rows/from_slices/from_flat receive (batch.rs:103,138,167): row-major [N*D];
  * the row-major -> dimension-major transpose runs on the device */
 innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t N, size_t D, innr_batch** out);
-/* synthetic corpus generated on the device: row i = generate_embedding(D, seed0 + i)
- * (examples/batch_demo.rs:167-170, 233-242). Used by the bench (30 GB cannot cross PCIe per run). */
-innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, uint64_t seed0, innr_batch** out);
+/* synthetic corpus generated on the device (the bench: 30 GB cannot cross PCIe per run). Row i of the batch is
+ * row (row0 + i) of the chosen stream, so range-partitioned shards of one logical corpus agree across GPUs.
+ *   INNR_GEN_EXAMPLE_LCG: generate_embedding(D, seed + row) (examples/batch_demo.rs:167-170, 233-242) -- the
+ *       reference example's generator; a one-parameter family of vectors, kept for the C1 plumbing shape.
+ *   INNR_GEN_UNIFORM: i.i.d. uniform[-1,1), the distribution of the reference's criterion inputs
+ *       (benches/batch.rs:11-21); stream = splitmix64 of the element index (oracle: orc_generate_uniform_rows). */
+#define INNR_GEN_EXAMPLE_LCG 0
+#define INNR_GEN_UNIFORM 1
+innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator, uint64_t seed, uint64_t row0,
+                                innr_batch** out);
 void innr_batch_free(innr_batch* b);
 size_t innr_batch_num_vectors(const innr_batch* b); /* batch.rs:199 */
 size_t innr_batch_dimension(const innr_batch* b);   /* batch.rs:204 */

@@ -6,9 +6,11 @@ imported from here.)
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 import threading
+import weakref
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +33,9 @@ KNN_EXACT = 1
 KNN_MFMA = 2
 
 MAX_K = 240
+
+GEN_EXAMPLE_LCG = 0
+GEN_UNIFORM = 1
 
 
 class InnrError(RuntimeError):
@@ -66,7 +71,7 @@ SIGNATURES = {
     "innr_version": (C.c_char_p, []),
     "innr_batch_upload_colmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "innr_batch_upload_rowmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
-    "innr_batch_generate": (C.c_int, [_vp, _sz, _sz, C.c_uint64, C.POINTER(_vp)]),
+    "innr_batch_generate": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_vp)]),
     "innr_batch_free": (None, [_vp]),
     "innr_batch_num_vectors": (_sz, [_vp]),
     "innr_batch_dimension": (_sz, [_vp]),
@@ -124,6 +129,7 @@ class Context:
         check(L.innr_ctx_create(int(device), C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self._children = weakref.WeakSet()  # device objects that hold a raw pointer to this ctx
 
     def set_stream(self, stream_ptr: int | None) -> None:
         check(load().innr_ctx_set_stream(self.handle, _vp(stream_ptr or 0)))
@@ -132,7 +138,10 @@ class Context:
         check(load().innr_ctx_synchronize(self.handle))
 
     def close(self) -> None:
+        """Free every batch created on this context, then the context (a batch must not outlive its ctx)."""
         if getattr(self, "handle", None):
+            for child in list(self._children):
+                child.close()
             load().innr_ctx_destroy(self.handle)
             self.handle = None
 
@@ -152,4 +161,5 @@ def default_context() -> Context:
     if _default_ctx is None:
         dev = int(os.environ.get("INNR_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _default_ctx = Context(dev)
+        atexit.register(_default_ctx.close)  # before interpreter teardown randomises __del__ order
     return _default_ctx

@@ -41,6 +41,7 @@ class VerticalBatch:
         self._n = int(num_vectors)
         self._d = int(dimension)
         self._ctx = ctx
+        ctx._children.add(self)
         self._host: Optional[np.ndarray] = None  # lazily downloaded dimension-major copy
 
     # ---- constructors --------------------------------------------------------------------------
@@ -84,13 +85,15 @@ class VerticalBatch:
         return cls._upload("innr_batch_upload_colmajor", col, num_vectors, dimension, ctx)
 
     @classmethod
-    def generate(cls, num_vectors: int, dimension: int, seed0: int = 0,
-                 ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
-        """Synthetic corpus made on the device: row i = generate_embedding(dimension, seed0 + i)
-        (examples/batch_demo.rs:167, 233-242)."""
+    def generate(cls, num_vectors: int, dimension: int, seed: int = 0, generator: int = _lib.GEN_UNIFORM,
+                 row0: int = 0, ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """Synthetic corpus made on the device; row i = row (row0 + i) of the chosen stream.
+        GEN_EXAMPLE_LCG: generate_embedding(dimension, seed + row) (examples/batch_demo.rs:167, 233-242);
+        GEN_UNIFORM: i.i.d. uniform[-1,1) (distribution of benches/batch.rs:11-21)."""
         ctx = ctx or default_context()
         h = C.c_void_p()
-        check(load().innr_batch_generate(ctx.handle, num_vectors, dimension, C.c_uint64(seed0), C.byref(h)))
+        check(load().innr_batch_generate(ctx.handle, num_vectors, dimension, int(generator), C.c_uint64(seed),
+                                         C.c_uint64(row0), C.byref(h)))
         return cls(h, num_vectors, dimension, ctx)
 
     # ---- accessors (batch.rs:187-219) --------------------------------------------------------------
@@ -123,7 +126,8 @@ class VerticalBatch:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
-            load().innr_batch_free(self._h)
+            if getattr(self._ctx, "handle", None):  # a closed ctx has already freed its batches
+                load().innr_batch_free(self._h)
             self._h = None
 
     def __del__(self):

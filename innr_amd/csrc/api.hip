@@ -77,6 +77,7 @@ struct innr_batch {
     size_t N = 0, D = 0, ldN = 0, Dpad = 0;
     float* V = nullptr;      // [Dpad][ldN]
     float* norms = nullptr;  // [ldN], lazily computed (exact batch_norms)
+    float* invn = nullptr;   // [ldN], 1/norm (0 for zero-norm vectors): GEMM engine's approximate cosine
     uint32_t* max_norm_bits = nullptr;
     bool norms_ready = false;
     float max_norm = 0.0f;
@@ -224,12 +225,139 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
     return INNR_OK;
 }
 
-// GEMM engine host driver (defined once the kernel exists)
-static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* dQn,
+// ---- GEMM engine -------------------------------------------------------------------------------------
+struct GemmPlan {
+    size_t Qpad;
+    uint32_t nqt, nslices, tps, KP, cap, nblocks;
+};
+
+static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
+    GemmPlan p;
+    p.Qpad = round_up(Q, kBQ);
+    p.nqt = (uint32_t)(p.Qpad / kBQ);
+    p.KP = pick_kp(kout, 16);
+    p.cap = (uint32_t)cand_cap((int)p.KP);
+    const uint32_t ntiles = (uint32_t)(b->ldN / kBC);
+    uint32_t target = (uint32_t)(2 * b->ctx->num_cus) / p.nqt;  // two resident blocks per CU
+    uint32_t ns = std::max(8u, target / 8 * 8);
+    ns = std::min(ns, (uint32_t)round_up(ntiles, 8));
+    p.nslices = ns;
+    p.tps = (ntiles + ns - 1) / ns;
+    p.nblocks = p.nqt * ns;
+    return p;
+}
+
+template <bool COS, int MODE>
+static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt, const float* invn, const float* invq,
+                               float* dump, size_t ld_dump) {
+    innr_ctx* c = b->ctx;
+    uint64_t* lists = c->lists.as<uint64_t>();
+    uint32_t* counts = c->counts.as<uint32_t>();
+    uint32_t* err = c->flags.as<uint32_t>();
+#define INNR_GEMM_LAUNCH(RR)                                                                                     \
+    gemm_filter_kernel<COS, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                 \
+        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, p.nqt, p.tps, invn, invq, lists, counts, p.KP, \
+        err, dump, ld_dump)
+    switch (p.cap) {
+        case 384: INNR_GEMM_LAUNCH(6); break;
+        case 512: INNR_GEMM_LAUNCH(8); break;
+        case 768: INNR_GEMM_LAUNCH(12); break;
+        default: INNR_GEMM_LAUNCH(20); break;
+    }
+#undef INNR_GEMM_LAUNCH
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+static innr_status ensure_invnorms(innr_batch* b) {
+    INNR_TRY(ensure_norms(b));
+    if (b->invn) return INNR_OK;
+    INNR_HIP_CHECK(hipMalloc((void**)&b->invn, b->ldN * sizeof(float)));
+    inv_norms_kernel<<<(unsigned)((b->ldN + 255) / 256), 256, 0, b->ctx->stream>>>(b->norms, b->ldN, b->N, b->invn);
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// Prepare K-major queries (+ norms, inverse norms). Leaves Qt in c->q_kmajor, norms in c->q_norm, inverses in c->misc.
+static innr_status prep_queries(innr_batch* b, const GemmPlan& p, const float* dQ, size_t Q, bool cos) {
+    innr_ctx* c = b->ctx;
+    INNR_TRY(c->q_kmajor.ensure(b->Dpad * p.Qpad * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
+    INNR_TRY(c->misc.ensure(p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
+    dim3 grid((unsigned)(p.Qpad / 32), (unsigned)(b->Dpad / 32));
+    transpose_queries_kernel<<<grid, 256, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, c->q_kmajor.as<float>(),
+                                                          p.Qpad, (uint32_t)b->Dpad);
+    INNR_HIP_CHECK(hipGetLastError());
+    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D,
+                                                                       c->q_norm.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    if (cos) {
+        inv_qnorms_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, Q,
+                                                                                  c->misc.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    return INNR_OK;
+}
+
+static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* /*dQn*/,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
                             float* gemm_ms) {
-    set_error("MFMA engine not built yet");
-    return INNR_E_UNSUPPORTED;
+    innr_ctx* c = b->ctx;
+    const bool cos = metric == INNR_METRIC_COSINE;
+    const GemmPlan p = plan_gemm(b, Q, kout);
+    INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot error bound
+    if (cos) INNR_TRY(ensure_invnorms(b));
+    INNR_TRY(prep_queries(b, p, dQ, Q, cos));
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
+    INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
+    float* invq = c->misc.as<float>();
+    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + p.Qpad * sizeof(float));
+    INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    if (cos) INNR_TRY((launch_gemm<true, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0)));
+    else INNR_TRY((launch_gemm<false, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+
+    select_topk_kernel<<<(unsigned)Q, kSelThreads, 0, c->stream>>>(c->lists.as<uint64_t>(), c->counts.as<uint32_t>(),
+                                                                  p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
+                                                                  c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>());
+    INNR_HIP_CHECK(hipGetLastError());
+
+    // |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum
+    const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
+    const float err_scale = cos ? cdu : cdu * b->max_norm;
+#define INNR_RESCORE(COSV, RKV)                                                                                     \
+    rescore_kernel<COSV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,          \
+                                                                 c->q_norm.as<float>(), c->sel.as<uint64_t>(),      \
+                                                                 c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout,   \
+                                                                 err_scale, b->index_base, d_out_idx, d_out_score,  \
+                                                                 fallback)
+    const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
+    if (cos) {
+        if (rk == 1) INNR_RESCORE(true, 1); else if (rk == 2) INNR_RESCORE(true, 2); else INNR_RESCORE(true, 4);
+    } else {
+        if (rk == 1) INNR_RESCORE(false, 1); else if (rk == 2) INNR_RESCORE(false, 2); else INNR_RESCORE(false, 4);
+    }
+#undef INNR_RESCORE
+    INNR_HIP_CHECK(hipGetLastError());
+
+    std::vector<uint32_t> fb(Q);
+    INNR_HIP_CHECK(hipMemcpyAsync(fb.data(), fallback, Q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
+    uint32_t nf = 0;
+    for (size_t q = 0; q < Q; ++q) {
+        if (!fb[q]) continue;
+        ++nf;  // margin proof failed (near-tie at the cut, or non-finite scores): redo this query exactly
+        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), q, 1, kout, d_out_idx, d_out_score));
+    }
+    *nfallback = nf;
+    *kept = p.KP;
+    return INNR_OK;
 }
 
 static innr_status check_errflag(innr_ctx* c) {
@@ -387,7 +515,12 @@ innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t 
     return INNR_OK;
 }
 
-innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, uint64_t seed0, innr_batch** out) {
+innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator, uint64_t seed, uint64_t row0,
+                                innr_batch** out) {
+    if (generator != INNR_GEN_EXAMPLE_LCG && generator != INNR_GEN_UNIFORM) {
+        set_error("unknown generator %d", generator);
+        return INNR_E_BAD_ARG;
+    }
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch(ctx, N, D, &b));
     if (N && D) {
@@ -397,7 +530,10 @@ innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, uint64_t seed
             return INNR_E_UNSUPPORTED;
         }
         dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)D);
-        generate_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)N, (uint32_t)D, seed0);
+        if (generator == INNR_GEN_UNIFORM)
+            generate_pdx_kernel<1><<<grid, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)N, (uint32_t)D, seed, row0);
+        else
+            generate_pdx_kernel<0><<<grid, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)N, (uint32_t)D, seed, row0);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -418,8 +554,47 @@ void innr_batch_free(innr_batch* b) {
     }
     if (b->V) (void)hipFree(b->V);
     if (b->norms) (void)hipFree(b->norms);
+    if (b->invn) (void)hipFree(b->invn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
     delete b;
+}
+
+// Test hook: copy out the GEMM engine's last candidate selection (approximate composites) and its error-bound inputs.
+innr_status innrdbg_last_selection(innr_batch* b, size_t Q, size_t KP, uint64_t* sel, uint32_t* cnt, float* qnorm,
+                                   float* info /* [0]=max_norm */) {
+    if (!b) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    INNR_HIP_CHECK(hipMemcpy(sel, c->sel.p, Q * KP * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    INNR_HIP_CHECK(hipMemcpy(cnt, c->sel_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    INNR_HIP_CHECK(hipMemcpy(qnorm, c->q_norm.p, Q * sizeof(float), hipMemcpyDeviceToHost));
+    info[0] = b->max_norm;
+    return INNR_OK;
+}
+
+// Test hook (not part of the ABI, not declared in include/innr_hip.h): dense approximate score matrix of the
+// GEMM engine, out[q*N + i], to check the MFMA operand/accumulator layout against the oracle.
+innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, float* out) {
+    if (!b || !queries || !out || D != b->D || Q == 0 || b->N == 0) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const bool cos = metric == INNR_METRIC_COSINE;
+    const GemmPlan p = plan_gemm(b, Q, 1);
+    INNR_TRY(ensure_norms(b));
+    if (cos) INNR_TRY(ensure_invnorms(b));
+    INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
+    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_TRY(prep_queries(b, p, c->q_row.as<float>(), Q, cos));
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
+    if (cos) INNR_TRY((launch_gemm<true, 1>(b, p, c->q_kmajor.as<float>(), b->invn, c->misc.as<float>(),
+                                            c->scores.as<float>(), b->ldN)));
+    else INNR_TRY((launch_gemm<false, 1>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
+    INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float),
+                                    b->N * sizeof(float), Q, hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return INNR_OK;
 }
 
 size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }

@@ -92,6 +92,14 @@ __device__ __forceinline__ float sub(float a, float b) {
 #pragma clang fp contract(off)
     return a - b;
 }
+// a - b where a NaN in b keeps its sign. gfx950's v_sub_f32 is a + (-b): it flips the sign of a propagated NaN,
+// while the host ISAs the reference runs on (x86 subss, aarch64 fsub) return the NaN operand unchanged -- and
+// total_cmp orders -NaN first / +NaN last, so the sign decides where a NaN distance lands in the result.
+__device__ __forceinline__ float sub_keepnan(float a, float b) {
+#pragma clang fp contract(off)
+    const float d = a - b;
+    return (b != b) ? b : d;
+}
 // acc + a*b with two roundings
 __device__ __forceinline__ float mad2(float acc, float a, float b) {
 #pragma clang fp contract(off)

@@ -1,3 +1,390 @@
-// kernels_gemm.h -- f32 MFMA GEMM engine (placeholder until the kernel lands in this round).
+// kernels_gemm.h -- the batched-query engine: Q x N scores as an f32 MFMA GEMM over the PDX corpus with a
+// fused per-query threshold-filter top-k, so the Q x N score matrix (41 GB at 1024 x 10M) never exists.
+//
+// Replaces the reference's per-query loop  batch_dot_into (src/batch.rs:284-297) + full stable sort
+// (:756-758) / batch_cosine_into epilogue (:713-727)  for a whole batch of queries.
+//
+// Roofline: MFMA-bound. 2*Q*N*D flop; v_mfma_f32_32x32x2_f32 = 64 flop/clk/SIMD = 157.3 TFLOP/s chip peak.
+// Arithmetic intensity at a 128 x 256 block tile is 2*128*256/(4*(128+256)) = 42.7 flop/B against L2, and
+// the corpus itself is streamed from HBM once per query tile (<= Q/256 times): far below the HBM roof.
+//
+// Mapping (CDNA4, wave64):
+//   S^T[corpus i][query j] = sum_d V[d][i] * Qt[d][j]     A = corpus (MFMA rows), B = queries (MFMA cols)
+//   Both operands are K-major in memory: the PDX layout V[d*ldN + i] IS the A operand's layout (lane l needs
+//   A[i = l&31][k = l>>5], i.e. 32 consecutive floats of one dimension row), and the queries are transposed
+//   once per call to Qt[d*Qpad + j]. No in-kernel transpose, every global and LDS access is contiguous.
+//   Block = 256 threads = 4 waves, tile 128 corpus x 256 queries x BK 16; wave w owns queries [64w, 64w+64)
+//   x all 128 corpus rows = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs).
+//   One ds_read_b128 per lane yields the A fragments of FOUR row tiles at once (tile rt holds corpus rows
+//   4r+rt), one ds_read_b64 the B fragments of TWO column tiles (tile ct holds queries 2c+ct): 2 LDS reads
+//   per 8 MFMAs, conflict-free (each wave instruction reads 1 KiB / 512 B of contiguous LDS).
+//   Staging: global_load_lds_dwordx4 (LDS-DMA), two LDS stages of 24 KiB, one barrier per K-step; 48 KiB LDS
+//   and <= 256 VGPRs keep two blocks resident per CU, so one block's epilogue (VALU) overlaps the other's
+//   MFMAs. The wave that owns a query owns its candidate list: no cross-wave synchronisation in the epilogue.
+//   Block -> (slice, query tile) is chosen so the query tiles of one corpus slice share an XCD (L2 reuse of
+//   the streamed corpus tile); placement only affects speed.
 #pragma once
+
 #include "common.h"
+#include "topk_dev.h"
+
+namespace innr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmThreads = 256;
+constexpr int kBC = 128;   // corpus rows per block tile
+constexpr int kBQ = 256;   // queries per block tile
+constexpr int kBK = 16;    // K-step
+constexpr int kGemmBurst = kBC;  // most appends one tile can make to one query's list
+
+struct alignas(16) GemmLds {
+    alignas(16) float A[2][kBK][kBC];  // 2 x 8 KiB
+    alignas(16) float B[2][kBK][kBQ];  // 2 x 16 KiB
+    uint32_t cnt[kBQ];
+    uint32_t thr[kBQ];
+};
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS [M0 .. M0 + 1 KiB), linear.
+// Written as inline asm on purpose: for the builtin, hipcc (ROCm 7.2) treats every later ds_read as aliasing
+// the pending DMA and drains vmcnt(0) before the first fragment read of the SAME K-step, which serialises
+// prefetch and compute. The asm form is invisible to that bookkeeping; the K-loop waits for it explicitly
+// (s_waitcnt vmcnt(0) before the barrier that publishes the stage). M0 is saved/restored around the DMA and
+// the SALU->M0->DMA hazard is padded with s_nop 0 inside the statement.
+__device__ __forceinline__ void glds16(const float* g, uint32_t lds_byte_addr_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_byte_addr_uniform)
+        : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+    return __builtin_amdgcn_readfirstlane(a);
+}
+
+// Stage one K-step (16 dimension rows) of the corpus tile and the query tile into LDS stage `st`.
+// Each wave issues 6 LDS-DMA instructions of 1 KiB: 2 for the corpus (2 rows of 512 B each) and 4 for the
+// queries (1 row of 1 KiB each). LDS destination = wave-uniform base + lane*16 (linear), source per lane.
+__device__ __forceinline__ void stage_tile(GemmLds& s, int st, const float* __restrict__ V, size_t ldN, size_t c0,
+                                           const float* __restrict__ Qt, size_t Qpad, size_t q0, uint32_t k0, int w,
+                                           int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 4 * w + 2 * j;  // rows row, row+1
+        const float* g = V + (size_t)(k0 + row + (lane >> 5)) * ldN + c0 + (size_t)(lane & 31) * 4;
+        glds16(g, lds_addr_uniform(&s.A[st][row][0]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 4 * w + j;
+        const float* g = Qt + (size_t)(k0 + row) * Qpad + q0 + (size_t)lane * 4;
+        glds16(g, lds_addr_uniform(&s.B[st][row][0]));
+    }
+}
+
+// Every LDS-DMA this wave issued has landed (they are the only asm-issued VMEM ops; compiler-issued loads and
+// stores of the epilogue share the counter, so this also drains those: once per K-step, after the MFMAs).
+__device__ __forceinline__ void wait_stage_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
+template <bool COS, int R, int MODE>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
+    const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
+    uint32_t nqt, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq,
+    uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
+    float* __restrict__ dump, size_t ld_dump) {
+    __shared__ GemmLds s;
+    constexpr uint32_t cap = 64 * R;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // blocks b, b+8, ... share an XCD (round-robin dispatch): give them the query tiles of ONE corpus slice
+    const uint32_t b = blockIdx.x;
+    const uint32_t slice = (b / (8 * nqt)) * 8 + (b & 7);
+    const uint32_t qt = (b >> 3) % nqt;
+    const size_t q0 = (size_t)qt * kBQ;
+    const uint32_t ntiles = (uint32_t)(ldN / kBC);
+    uint32_t t0 = slice * tiles_per_slice, t1 = t0 + tiles_per_slice;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 > t1) t0 = t1;
+    const uint32_t nk = Dpad / kBK;
+    const uint32_t total = (t1 - t0) * nk;
+
+    s.cnt[threadIdx.x] = 0;  // kBQ == kGemmThreads
+    s.thr[threadIdx.x] = 0;
+    uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
+
+    if (total > 0) stage_tile(s, 0, V, ldN, (size_t)t0 * kBC, Qt, Qpad, q0, 0, w, lane);
+    wait_stage_landed();
+    __syncthreads();  // stage 0 visible to every wave
+
+    uint32_t tile = t0, ks = 0;
+    for (uint32_t step = 0; step < total; ++step) {
+        const int st = step & 1;
+        // prefetch the next K-step (possibly the next tile's first) into the other stage
+        if (step + 1 < total) {
+            uint32_t ntile = tile, nks = ks + 1;
+            if (nks == nk) {
+                nks = 0;
+                ntile = tile + 1;
+            }
+            stage_tile(s, st ^ 1, V, ldN, (size_t)ntile * kBC, Qt, Qpad, q0, nks * kBK, w, lane);
+        }
+        // 8 k-pairs x (4 x 2) MFMAs on the current stage
+#pragma unroll
+        for (int kp = 0; kp < kBK / 2; ++kp) {
+            const float4 av = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+            const float2 bv = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
+            const float a[4] = {av.x, av.y, av.z, av.w};
+            const float bb[2] = {bv.x, bv.y};
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bb[ct], acc[rt][ct], 0, 0, 0);
+        }
+
+        if (ks + 1 == nk) {
+            // ---------------- epilogue for corpus tile `tile` ----------------
+            const size_t tb = (size_t)tile * kBC;
+            const int half = lane >> 5, C = lane & 31;
+            if (MODE == 1) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const size_t q = q0 + 64 * w + 2 * C + ct;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
+                            float v = acc[rt][ct][g];
+                            if (COS) v = v * invn[i] * invq[q];
+                            dump[q * ld_dump + i] = v;
+                        }
+                }
+            } else {
+                // scale (cosine) and convert to total-order keys in place; track this lane's best per query
+                uint32_t best[2] = {0, 0};
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {  // 16 consecutive corpus rows: tb + 4*(8*gq + 4*half) + [0,16)
+                    float sc[16];
+                    if (COS) {
+                        const float4* p = reinterpret_cast<const float4*>(invn + tb + 4 * (8 * gq + 4 * half));
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const float4 t = p[x];
+                            sc[4 * x + 0] = t.x; sc[4 * x + 1] = t.y; sc[4 * x + 2] = t.z; sc[4 * x + 3] = t.w;
+                        }
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const float iq = COS ? invq[q0 + 64 * w + 2 * C + ct] : 1.0f;
+#pragma unroll
+                        for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt) {
+                                float v = acc[rt][ct][4 * gq + g3];
+                                if (COS) v = v * sc[4 * g3 + rt] * iq;
+                                const uint32_t o = f32_ord(v);
+                                acc[rt][ct][4 * gq + g3] = __uint_as_float(o);
+                                best[ct] = best[ct] > o ? best[ct] : o;
+                            }
+                    }
+                }
+                uint32_t thr[2];
+                thr[0] = __hip_atomic_load(&s.thr[64 * w + 2 * C + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                thr[1] = __hip_atomic_load(&s.thr[64 * w + 2 * C + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const bool any_hit = (best[0] >= thr[0]) || (best[1] >= thr[1]);
+                if (__any(any_hit)) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const int ql = 64 * w + 2 * C + ct;
+                        uint64_t* lq = my_lists + (size_t)ql * cap;
+                        if (best[ct] >= thr[ct]) {
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                                for (int g = 0; g < 16; ++g) {
+                                    const uint32_t o = __float_as_uint(acc[rt][ct][g]);
+                                    const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
+                                    if (o >= thr[ct] && i < N)
+                                        cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // compact the lists of this wave's queries that are running out of room
+                    const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    unsigned long long need = __ballot(c > cap - kGemmBurst);
+                    while (need) {
+                        const int j = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const int ql = 64 * w + j;
+                        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                        uint32_t t;
+                        const uint32_t keep = wave_compact<R>(my_lists + (size_t)ql * cap, cj, KP, &t);
+                        if (lane == 0) {
+                            s.cnt[ql] = keep;
+                            s.thr[ql] = t;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
+            ks = 0;
+            ++tile;
+        } else {
+            ++ks;
+        }
+        wait_stage_landed();  // this wave's share of the next stage is in LDS ...
+        __syncthreads();      // ... and so is everyone else's; the stage just consumed is free to overwrite
+    }
+
+    if (MODE == 0) {
+        // leave <= KP entries per list and publish the counts (every query of the tile, padded ones too)
+        const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned long long need = __ballot(c > KP);
+        uint32_t mine = c;
+        while (need) {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)(64 * w + j) * cap, cj, KP, &t);
+            if (lane == j) mine = keep;
+        }
+        counts[(size_t)slice * Qpad + q0 + 64 * w + lane] = mine;
+    }
+}
+
+// ---- helpers around the GEMM ------------------------------------------------------------------------
+// Qt[d*Qpad + j] = Q[j*D + d] (zero padded to Dpad x Qpad)
+__global__ __launch_bounds__(256) void transpose_queries_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D,
+                                                                 float* __restrict__ Qt, size_t Qpad, uint32_t Dpad) {
+    __shared__ float tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t jb = blockIdx.x * 32, db = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const uint32_t j = jb + ty + r, d = db + tx;
+        tile[ty + r][tx] = (j < Q && d < D) ? Qm[(size_t)j * D + d] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const uint32_t d = db + ty + r, j = jb + tx;
+        if (d < Dpad && j < Qpad) Qt[(size_t)d * Qpad + j] = tile[tx][ty + r];
+    }
+}
+
+// inv[i] = x > eps ? 1/x : 0   (scale factors for the approximate cosine used only for candidate selection)
+__global__ void inv_norms_kernel(const float* __restrict__ x, size_t n, size_t n_valid, float* __restrict__ inv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = (i < n_valid) ? x[i] : 0.0f;
+    inv[i] = (v > INNR_NORM_EPSILON) ? 1.0f / v : 0.0f;
+}
+__global__ void inv_qnorms_kernel(const float* __restrict__ x, size_t n, size_t n_valid, float* __restrict__ inv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = (i < n_valid) ? x[i] : 0.0f;
+    inv[i] = (v >= INNR_NORM_EPSILON) ? 1.0f / v : 0.0f;  // batch.rs:716: whole output 0 when ||q|| < eps
+}
+
+// Exact re-score + final ordering + margin proof. One wave per query.
+//   sel[q][0..KP): best-first composites by APPROXIMATE (MFMA) score; sel_cnt[q] of them valid.
+//   Each candidate is re-scored in the reference's arithmetic order (ex::mad2 over d ascending; cosine
+//   epilogue batch.rs:721-727), candidates are ranked by (exact score total order desc, index asc) and the
+//   best kout are written. Proof obligation for "no vector outside the candidate set can belong to the true
+//   top-k": every outsider has approx <= T (the KP-th approximate score) and |approx - exact| <= E, so it is
+//   enough that exact(k-th best candidate) > T + E. Failing queries are flagged for the exact engine.
+template <bool COS, int RK>
+__global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V, size_t ldN, uint32_t D,
+                                                     const float* __restrict__ Qm, const float* __restrict__ norms,
+                                                     const float* __restrict__ qnorm, const uint64_t* __restrict__ sel,
+                                                     const uint32_t* __restrict__ sel_cnt, uint32_t KP, uint32_t kout,
+                                                     float err_scale, uint64_t index_base,
+                                                     uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                     uint32_t* __restrict__ fallback) {
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t cnt = sel_cnt[q];
+    const float* qv = Qm + (size_t)q * D;
+    const float qn = qnorm[q];
+    uint64_t e[RK];
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+        const uint32_t c = r * 64 + lane;
+        e[r] = 0;
+        if (c < cnt) {
+            const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
+            const float* col = V + i;
+            float acc = 0.0f;
+#pragma unroll 8
+            for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
+            if (COS) {
+                const float vn = norms[i];
+                acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
+            }
+            e[r] = cand_make(f32_ord(acc), i);
+        }
+    }
+    uint32_t rank[RK];
+#pragma unroll
+    for (int r = 0; r < RK; ++r) rank[r] = 0;
+#pragma unroll
+    for (int r2 = 0; r2 < RK; ++r2) {
+        if ((uint32_t)(r2 * 64) < cnt) {
+            const int lim = (cnt - r2 * 64) < 64u ? (int)(cnt - r2 * 64) : 64;
+            for (int l = 0; l < lim; ++l) {
+                const uint64_t bcast = readlane_u64(e[r2], l);
+#pragma unroll
+                for (int r = 0; r < RK; ++r) rank[r] += (bcast > e[r]) ? 1u : 0u;
+            }
+        }
+    }
+    uint32_t kth_bits = 0;
+    bool have_kth = false;
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+        const uint32_t c = r * 64 + lane;
+        if (c < cnt && rank[r] < kout) {
+            out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
+            out_score[(size_t)q * kout + rank[r]] = ord_f32(cand_pref(e[r]));
+        }
+        if (c < cnt && rank[r] == kout - 1) {
+            kth_bits = cand_pref(e[r]);
+            have_kth = true;
+        }
+    }
+    // margin proof (one lane holds the k-th best exact score)
+    bool bad = false;
+    if (have_kth && cnt == KP) {  // cnt < KP: every corpus vector is a candidate, nothing to prove
+        const float exact_k = ord_f32(kth_bits);
+        const float T = ord_f32(cand_pref(sel[(size_t)q * KP + KP - 1]));
+        const float E = COS ? err_scale : err_scale * qn;
+        bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
+    }
+    if (__any(bad) && lane == 0) fallback[q] = 1;
+}
+
+}  // namespace innr

@@ -19,17 +19,32 @@ __device__ __forceinline__ float lcg_embedding(uint64_t seed, uint32_t d) {
     return ex::sub(ex::mul(ex::mul(f, 4.656612873077393e-10f /* 2^-31: exact divide */), 2.0f), 1.0f);
 }
 
-// one thread = 4 consecutive vectors of one dimension row
-__global__ void generate_pdx_kernel(float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, uint64_t seed0) {
+// i.i.d. uniform[-1,1): splitmix64 finaliser of the element index, top 24 bits -> k*2^-23 - 1 (exact in f32).
+// Same stream as the CPU checker's orc_uniform_elem (distribution of benches/batch.rs:11-21).
+__device__ __forceinline__ float uniform_embedding(uint64_t seed, uint64_t row, uint32_t D, uint32_t d) {
+    uint64_t z = seed * 0xD1342543DE82EF95ull + (row * (uint64_t)D + d) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return ex::sub(ex::mul(__uint2float_rn((uint32_t)(z >> 40)), 1.1920928955078125e-07f /* 2^-23 */), 1.0f);
+}
+
+// one thread = 4 consecutive vectors of one dimension row.
+// GEN 0: row i = generate_embedding(D, seed + i) (the reference example's generator);
+// GEN 1: row i = uniform stream `seed`, row index row0 + i.
+template <int GEN>
+__global__ void generate_pdx_kernel(float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, uint64_t seed,
+                                    uint64_t row0) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const uint32_t d = blockIdx.y;
     if (i4 >= ldN || d >= D) return;
-    float4 v;
-    v.x = (i4 + 0 < N) ? lcg_embedding(seed0 + i4 + 0, d) : 0.0f;
-    v.y = (i4 + 1 < N) ? lcg_embedding(seed0 + i4 + 1, d) : 0.0f;
-    v.z = (i4 + 2 < N) ? lcg_embedding(seed0 + i4 + 2, d) : 0.0f;
-    v.w = (i4 + 3 < N) ? lcg_embedding(seed0 + i4 + 3, d) : 0.0f;
-    *reinterpret_cast<float4*>(V + (size_t)d * ldN + i4) = v;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t i = i4 + c;
+        v[c] = (i < N) ? (GEN == 0 ? lcg_embedding(seed + row0 + i, d) : uniform_embedding(seed, row0 + i, D, d)) : 0.0f;
+    }
+    *reinterpret_cast<float4*>(V + (size_t)d * ldN + i4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // VerticalBatch::from_flat (src/batch.rs:167-183) on the device: rows[(i0+i)*D + d] -> V[d*ldN + i0 + i].

@@ -32,7 +32,8 @@ __device__ __forceinline__ void scan_accumulate(const float* __restrict__ V, siz
         for (int j = 0; j < QB; ++j) {
             const float q = Qm[(size_t)j * ldq + d];  // wave-uniform -> scalar load
             if (L2) {  // batch.rs:262-263: diff = q_d - v_d; dist += diff*diff
-                const float d0 = ex::sub(q, v.x), d1 = ex::sub(q, v.y), d2 = ex::sub(q, v.z), d3 = ex::sub(q, v.w);
+                const float d0 = ex::sub_keepnan(q, v.x), d1 = ex::sub_keepnan(q, v.y), d2 = ex::sub_keepnan(q, v.z),
+                            d3 = ex::sub_keepnan(q, v.w);
                 acc[j][0] = ex::mad2(acc[j][0], d0, d0);
                 acc[j][1] = ex::mad2(acc[j][1], d1, d1);
                 acc[j][2] = ex::mad2(acc[j][2], d2, d2);

@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
     sig("orc_generate_embedding", None, _sz, C.c_uint64, _f32p)
     sig("orc_generate_normalized", None, _sz, C.c_uint64, _f32p)
     sig("orc_generate_rows", None, _sz, _sz, C.c_uint64, C.c_int, _f32p)
+    sig("orc_generate_uniform_rows", None, _sz, _sz, C.c_uint64, C.c_uint64, _f32p)
     _lib = L
     return L
 
@@ -352,4 +353,12 @@ def generate_corpus(n: int, dim: int, seed0: int = 0, normalized: bool = False) 
     """Row-major (n, dim) corpus, row i = generate_embedding(dim, seed0 + i) (batch_demo.rs:167)."""
     out = np.empty((n, dim), dtype=np.float32)
     lib().orc_generate_rows(n, dim, C.c_uint64(seed0 & 0xFFFFFFFFFFFFFFFF), 1 if normalized else 0, _p(out))
+    return out
+
+
+def generate_uniform(n: int, dim: int, seed: int = 0, row0: int = 0) -> np.ndarray:
+    """Row-major (n, dim) i.i.d. uniform[-1,1) rows row0..row0+n of stream `seed` (bit-identical to the
+    device generator INNR_GEN_UNIFORM; distribution of the reference's criterion benches)."""
+    out = np.empty((n, dim), dtype=np.float32)
+    lib().orc_generate_uniform_rows(n, dim, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_uint64(row0), _p(out))
     return out

@@ -741,3 +741,23 @@ void orc_generate_rows(size_t n, size_t dim, uint64_t seed0, int normalized, flo
         else orc_generate_embedding(dim, seed0 + i, out + i * dim);
     }
 }
+
+/*
+ * i.i.d. uniform[-1,1) rows: the DISTRIBUTION of the reference's criterion inputs (benches/batch.rs:11-21,
+ * StdRng uniform(-1,1)); the stream itself is this repo's (the rand crate is not reproducible here): a
+ * splitmix64 finaliser of the element index, top 24 bits -> k * 2^-23 - 1 (exact in f32, no rounding).
+ * The example generator above is a one-parameter family (row s+1 = row s shifted by a constant mod 1), so
+ * it is kept for the C1 plumbing shape only; ranking-sensitive tests and the bench use this one.
+ */
+static inline float orc_uniform_elem(uint64_t seed, uint64_t elem) {
+    uint64_t z = seed * 0xD1342543DE82EF95ULL + elem + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 8388608.0f) - 1.0f;
+}
+
+void orc_generate_uniform_rows(size_t n, size_t dim, uint64_t seed, uint64_t row0, float* out) {
+    for (size_t i = 0; i < n; ++i)
+        for (size_t d = 0; d < dim; ++d) out[i * dim + d] = orc_uniform_elem(seed, (row0 + i) * (uint64_t)dim + d);
+}

@@ -103,6 +103,8 @@ void orc_generate_embedding(size_t dim, uint64_t seed, float* out);   /* example
 void orc_generate_normalized(size_t dim, uint64_t seed, float* out);  /* examples/maxsim_colbert.rs:212-228 */
 /* rows[i] = generate_embedding(dim, seed0 + i) (batch_demo.rs:167); normalized != 0 -> generate_normalized */
 void orc_generate_rows(size_t n, size_t dim, uint64_t seed0, int normalized, float* out_rowmajor);
+/* i.i.d. uniform[-1,1) rows row0..row0+n (distribution of benches/batch.rs:11-21; see innr_oracle.c) */
+void orc_generate_uniform_rows(size_t n, size_t dim, uint64_t seed, uint64_t row0, float* out_rowmajor);
 
 #ifdef __cplusplus
 }

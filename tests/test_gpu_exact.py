@@ -27,12 +27,16 @@ def innr():
     return innr_amd
 
 
-def _corpus(n, dim, seed0=0):
-    rows = oracle.generate_corpus(n, dim, seed0)
+def _corpus(n, dim, seed0=0, uniform=False):
+    """LCG rows (the reference example's generator, examples/batch_demo.rs:167) or i.i.d. uniform[-1,1) rows
+    (the distribution of the reference's criterion benches, benches/batch.rs:11-21)."""
+    rows = oracle.generate_uniform(n, dim, seed0) if uniform else oracle.generate_corpus(n, dim, seed0)
     return rows, oracle.from_rows(rows)
 
 
-def _queries(nq, dim, seed0=50_000):
+def _queries(nq, dim, seed0=50_000, uniform=False):
+    if uniform:
+        return oracle.generate_uniform(nq, dim, seed0 + 0x5EED)
     return np.stack([oracle.generate_embedding(dim, seed0 + j) for j in range(nq)])
 
 
@@ -79,9 +83,15 @@ def test_layout_errors_and_empty(B, innr):
 
 
 @pytest.mark.parametrize("n,dim,seed0", [(1000, 128, 0), (257, 33, 1 << 40), (5000, 768, 12345)])
-def test_device_generator_bit_exact(B, n, dim, seed0):
-    vb = B.VerticalBatch.generate(n, dim, seed0)
+def test_device_generator_bit_exact(B, innr, n, dim, seed0):
+    vb = B.VerticalBatch.generate(n, dim, seed0, generator=innr.GEN_EXAMPLE_LCG)
     assert np.array_equal(vb.data(), oracle.from_rows(oracle.generate_corpus(n, dim, seed0)))
+    vb = B.VerticalBatch.generate(n, dim, seed0, generator=innr.GEN_EXAMPLE_LCG, row0=17)
+    assert np.array_equal(vb.data(), oracle.from_rows(oracle.generate_corpus(n, dim, seed0 + 17)))
+    vb = B.VerticalBatch.generate(n, dim, seed0)  # default: uniform stream
+    assert np.array_equal(vb.data(), oracle.from_rows(oracle.generate_uniform(n, dim, seed0)))
+    vb = B.VerticalBatch.generate(n, dim, seed0, row0=12_345_678_901)
+    assert np.array_equal(vb.data(), oracle.from_rows(oracle.generate_uniform(n, dim, seed0, row0=12_345_678_901)))
 
 
 # ------------------------------------------------------------------------------- bit-exact scans
@@ -184,6 +194,12 @@ def test_knn_exact_single_query_api_matches_reference_shape(B, innr):
         oi, os_ = ofn(q, data, 10)
         assert isinstance(r, B.BatchKnnResult) and r.indices == oi.tolist() and np.array_equal(np.float32(r.scores), os_)
     assert B.batch_knn_dot(q, vb, 0).indices == [] and B.batch_knn(q, vb, 0).scores == []
+
+
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
+def test_knn_exact_uniform_data(B, innr, metric):
+    rows, data = _corpus(20_000, 96, 3, uniform=True)
+    _check_knn(B, innr, metric, rows, data, _queries(24, 96, 8, uniform=True), 20, innr.KNN_EXACT)
 
 
 def test_knn_k_limit_is_loud(B, innr):

@@ -1,0 +1,202 @@
+"""GPU parity tests, part 2: the f32-MFMA GEMM engine (fused top-k filter + exact re-score + margin proof).
+Bar (BASELINE.json north_star): top-k index lists identical to the portable CPU path, scores within 1e-4
+relative -- the engine actually delivers bit-identical scores because every reported score is re-computed in
+the reference's arithmetic order."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from test_gpu_exact import _check_knn, _corpus, _queries, bits_equal, same_knn
+
+
+@pytest.fixture(scope="module")
+def B():
+    from innr_amd import batch
+    return batch
+
+
+@pytest.fixture(scope="module")
+def innr():
+    import innr_amd
+    return innr_amd
+
+
+def _dense_scores(vb, metric, queries):
+    from innr_amd import _lib
+    L = _lib.load()
+    fn = L.innrdbg_gemm_scores  # test hook, deliberately outside include/innr_hip.h
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    q = np.ascontiguousarray(queries, np.float32)
+    out = np.empty((q.shape[0], vb.num_vectors()), np.float32)
+    _lib.check(fn(vb._h, metric, q.ctypes.data, q.shape[0], q.shape[1], out.ctypes.data))
+    return out
+
+
+def _mfma_knn_checked(B, innr, metric, rows, data, qs, k, max_fallback):
+    """MFMA engine == oracle, AND the GEMM path itself did the work (few/no exact-engine fallbacks)."""
+    vb = _check_knn(B, innr, metric, rows, data, qs, k, innr.KNN_MFMA)
+    st = innr.KnnStats()
+    fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi}[metric]
+    fn(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+    assert st.engine == innr.KNN_MFMA and st.queries_fallback <= max_fallback, st.queries_fallback
+    return vb
+
+
+# ------------------------------------------------------------------------------- operand / accumulator layout
+@pytest.mark.parametrize("n,dim,nq", [(128, 16, 1), (300, 33, 5), (1000, 128, 70), (257, 2, 300), (5000, 768, 33)])
+def test_gemm_dense_scores_match_oracle(B, innr, n, dim, nq):
+    # tolerance: the reference's own SIMD-vs-scalar convention, 1e-4 * sum|a*b| + 1e-4 (tests/property_tests.rs:408)
+    rows, data = _corpus(n, dim, 5, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    qs = _queries(nq, dim, 777, uniform=True)
+    got = _dense_scores(vb, innr.METRIC_DOT, qs)
+    norms = oracle.batch_norms(data)
+    gotc = _dense_scores(vb, innr.METRIC_COSINE, qs)
+    for j in range(nq):
+        exp = oracle.batch_dot(qs[j], data)
+        tol = 1e-4 * (np.abs(qs[j])[:, None] * np.abs(data)).sum(axis=0) + 1e-4
+        assert np.all(np.abs(got[j] - exp) <= tol), (j, np.abs(got[j] - exp).max())
+        expc = oracle.batch_cosine(qs[j], data, norms)
+        assert np.all(np.abs(gotc[j] - expc) <= 2e-4), (j, np.abs(gotc[j] - expc).max())
+
+
+def test_gemm_layout_asymmetric_integers(B, innr):
+    # exact small integers: every product and partial sum is exact in f32, so the MFMA result must EQUAL the
+    # oracle's; an asymmetric corpus catches a transposed accumulator map (guide: "A=I with asymmetric B")
+    n, dim, nq = 384, 48, 260
+    rows = ((np.arange(n)[:, None] * 7 + np.arange(dim)[None, :] * 3) % 11 - 5).astype(np.float32)
+    qs = ((np.arange(nq)[:, None] * 5 + np.arange(dim)[None, :]) % 7 - 3).astype(np.float32)
+    vb = B.VerticalBatch.from_rows(rows)
+    got = _dense_scores(vb, innr.METRIC_DOT, qs)
+    exp = (qs.astype(np.int64) @ rows.astype(np.int64).T).astype(np.float32)
+    assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------------------- kNN parity
+@pytest.mark.parametrize("metric", ["dot", "cos"])
+def test_knn_mfma_c1_shape(B, innr, metric):
+    # BASELINE.json configs[0] shape (10K x 128, 100 queries, k = 10) on the GEMM engine, uniform data
+    rows, data = _corpus(10_000, 128, 0, uniform=True)
+    _mfma_knn_checked(B, innr, metric, rows, data, _queries(100, 128, uniform=True), 10, max_fallback=1)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cos"])
+def test_knn_mfma_c1_example_generator(B, innr, metric):
+    # the reference example's own LCG data (examples/batch_demo.rs:167-170): a one-parameter family with seas of
+    # near-ties, so most margin proofs fail and those queries are redone on the exact engine. Results must
+    # still be identical.
+    rows, data = _corpus(10_000, 128, 0)
+    _check_knn(B, innr, metric, rows, data, _queries(100, 128), 10, innr.KNN_MFMA)
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(1, 4, 1, 1), (5, 3, 2, 10), (255, 16, 3, 7), (257, 33, 5, 16), (1000, 64, 9, 33),
+                                        (3000, 20, 300, 100), (2049, 8, 4, 240), (20_000, 100, 513, 10)])
+def test_knn_mfma_ragged(B, innr, n, dim, nq, k):
+    rows, data = _corpus(n, dim, 77, uniform=True)
+    vb = None
+    for metric in ("dot", "cos"):
+        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(nq, dim, 4242, uniform=True), k,
+                        innr.KNN_MFMA)
+
+
+def test_knn_mfma_many_tiles_and_compactions(B, innr):
+    # 200K x 32 on few slices: candidate lists fill and compact repeatedly inside the GEMM kernel
+    rows, data = _corpus(200_000, 32, 11, uniform=True)
+    qs = _queries(40, 32, 99, uniform=True)
+    _mfma_knn_checked(B, innr, "dot", rows, data, qs, 10, max_fallback=2)
+    _mfma_knn_checked(B, innr, "cos", rows, data, qs, 100, max_fallback=2)
+
+
+def test_knn_mfma_ties_zero_query_and_stats(B, innr):
+    base = oracle.generate_uniform(700, 24, 9)
+    rows = np.concatenate([base, base, base[::-1]])  # every vector three times: exact ties at every rank
+    data = oracle.from_rows(rows)
+    qs = np.concatenate([_queries(20, 24, 31, uniform=True), np.zeros((1, 24), np.float32)])
+    for metric in ("dot", "cos"):
+        _check_knn(B, innr, metric, rows, data, qs, 12, innr.KNN_MFMA)
+    vb = B.VerticalBatch.from_rows(rows)
+    st = innr.KnnStats()
+    B.batch_knn_dot_multi(qs, vb, 12, engine=innr.KNN_MFMA, stats=st)
+    assert st.engine == innr.KNN_MFMA and st.candidates_kept == 32 and st.gemm_ms > 0.0
+    # 12 = 4 triples: the cut falls between groups, the proof holds for random queries; the all-zero query ties
+    # every vector at 0.0 and can only be settled by the exact engine
+    assert 1 <= st.queries_fallback <= 4
+
+
+def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
+    rows = oracle.generate_uniform(4000, 32, 1)
+    rows[17, 3] = np.nan
+    rows[300, 0] = np.inf
+    data = oracle.from_rows(rows)
+    qs = _queries(6, 32, 5, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    st = innr.KnnStats()
+    idx, sc = B.batch_knn_dot_multi(qs, vb, 5, engine=innr.KNN_MFMA, stats=st)
+    assert st.queries_fallback == len(qs)  # the error bound is not finite: nothing can be proven, all redone
+    for j, q in enumerate(qs):
+        oi, os_ = oracle.batch_knn_dot(q, data, 5)
+        assert same_knn("dot", idx[j], sc[j], oi, os_)
+
+
+def test_knn_auto_engine_selection(B, innr):
+    vb = B.VerticalBatch.generate(3000, 64, 0)
+    st = innr.KnnStats()
+    B.batch_knn_dot_multi(_queries(4, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_EXACT
+    B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_MFMA
+    B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)  # L2 stays on the exact engine
+    assert st.engine == innr.KNN_EXACT
+
+
+# ------------------------------------------------------------------------------- larger sizes: engine agreement
+def test_engines_agree_1m(B, innr):
+    # 1M x 128 (the oracle would need minutes for 256 queries): the exact engine is pinned to the oracle above,
+    # so agreement of the two engines carries parity to this size.
+    vb = B.VerticalBatch.generate(1_000_000, 128, 0)
+    qs = _queries(256, 128, 10_000_000, uniform=True)
+    for fn in (B.batch_knn_dot_multi, B.batch_knn_cosine_multi):
+        st = innr.KnnStats()
+        i1, s1 = fn(qs, vb, 10, engine=innr.KNN_MFMA, stats=st)
+        i2, s2 = fn(qs[:64], vb, 10, engine=innr.KNN_EXACT)
+        assert np.array_equal(i1[:64], i2) and bits_equal(s1[:64], s2)
+        assert st.queries_fallback <= 2, st.queries_fallback
+    # spot-check 3 queries of the same corpus against the CPU oracle
+    data = oracle.from_rows(oracle.generate_uniform(1_000_000, 128, 0))
+    i1, s1 = B.batch_knn_dot_multi(qs[:3], vb, 10, engine=innr.KNN_MFMA)
+    for j in range(3):
+        oi, os_ = oracle.batch_knn_dot(qs[j], data, 10)
+        assert same_knn("dot", i1[j], s1[j], oi, os_)
+
+
+def test_full_size_properties_c2(B, innr):
+    # BASELINE.json configs[1]: 10M x 768 f32, 1024 queries, k = 10 -- through size-independent properties:
+    #  (1) self-match: a query equal to corpus row r must rank r first under cosine with score ~ 1;
+    #  (2) results sorted best-first, indices unique and in range;
+    #  (3) the GEMM engine equals the bit-exact engine on a subset of the same queries.
+    n, dim, nq, k = 10_000_000, 768, 1024, 10
+    vb = B.VerticalBatch.generate(n, dim, 0)
+    picks = (np.arange(nq, dtype=np.int64) * 9_765 + 123) % n
+    qs = np.concatenate([oracle.generate_uniform(1, dim, 0, row0=int(r)) for r in picks])  # query j = corpus row picks[j]
+    st = innr.KnnStats()
+    idx, sc = B.batch_knn_cosine_multi(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+    assert idx.shape == (nq, k)
+    assert np.array_equal(idx[:, 0].astype(np.int64), picks)
+    assert np.all(np.abs(sc[:, 0] - 1.0) < 1e-5)
+    assert np.all(sc[:, :-1] >= sc[:, 1:]) and idx.max() < n
+    assert all(len(set(r.tolist())) == k for r in idx)
+    assert st.queries_fallback <= 4, st.queries_fallback
+    i2, s2 = B.batch_knn_cosine_multi(qs[:16], vb, k, engine=innr.KNN_EXACT)
+    assert np.array_equal(idx[:16], i2) and bits_equal(sc[:16], s2)
+    idx, sc = B.batch_knn_dot_multi(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+    i2, s2 = B.batch_knn_dot_multi(qs[:16], vb, k, engine=innr.KNN_EXACT)
+    assert np.array_equal(idx[:16], i2) and bits_equal(sc[:16], s2)
+    assert np.all(sc[:, :-1] >= sc[:, 1:]) and st.queries_fallback <= 4
+    print(f"C2 dot: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+Workload (configs[1]): batch_knn_dot, f32, 10M x 768 corpus per GPU, 1024-query batch, k = 10.
+A "step" = one pass of the hot path over one query batch: innr_batch_knn_dev (query transpose, f32-MFMA GEMM
+with fused top-k filter, cross-slice select, exact re-score + margin proof [, exact-engine redo of unproven
+queries]) with the corpus and the queries already resident in HBM; for N > 1 GPUs (one process per GPU, corpus
+range-partitioned, weak scaling: 10M vectors PER GPU) the step also includes the RCCL all-gather of the
+per-shard top-k and the merge. value = vectors scanned per second = Q * N_total / step time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the GEMM, timed live with HIP events on
+the stream it is launched on) and `cpu_baseline` (the CPU oracle = "port" of innr's portable path, single
+thread like the reference, on a bounded sample) objects described in DESIGN.md.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 flop/clk x 2.4 GHz
+
+
+def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
+    """Oracle (port of batch_knn_dot: src/batch.rs:742-764 = scan :284-297 + full stable sort :756-758) on the
+    host, ONE thread (the reference has no threading), on a 1M-vector sub-sample of the same uniform stream."""
+    import numpy as np
+    import oracle
+
+    n = 1_000_000
+    rows = oracle.generate_uniform(n, dim, 0)
+    data = oracle.from_rows(rows)
+    del rows
+    queries = oracle.generate_uniform(64, dim, 0xBE7C)
+    oracle.batch_knn_dot(queries[0], data[:, :1000].copy(), k)  # warm the library
+    done, t0 = 0, time.perf_counter()
+    while done < len(queries):
+        oracle.batch_knn_dot(queries[done], data, k)
+        done += 1
+        if time.perf_counter() - t0 >= budget_s or done >= 16:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": done * n / dt,
+        "unit": "vectors/s",
+        "cores": 1,
+        "kind": "port",
+        "qps_at_10M": (done / dt) * (n / 10_000_000),
+        "sample": f"oracle batch_knn_dot (scan + full stable sort), {done} queries x {n} x {dim} f32 uniform(-1,1), k={k}, "
+                  f"{dt:.1f} s on 1 host thread; the scan is O(N) so vectors/s carries to 10M",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", choices=["dot", "cosine"], default="dot")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import oracle  # queries come from the shared uniform stream (generation only; nothing on the timed path)
+    from innr_amd import KNN_MFMA, METRIC_COSINE, METRIC_DOT, Context, KnnStats
+    from innr_amd import batch as B
+    from innr_amd.dist import ShardedKnn
+
+    metric = METRIC_DOT if args.metric == "dot" else METRIC_COSINE
+    ctx = Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream for the kernels and the collective
+    n_total = args.n_per_gpu * world
+    sk = ShardedKnn(n_total, rank=rank, world=world) if world > 1 else None
+    row0 = rank * args.n_per_gpu
+    vb = B.VerticalBatch.generate(args.n_per_gpu, args.dim, seed=0, row0=row0, ctx=ctx)  # resident in HBM
+    if sk is not None:
+        sk.attach_gpu_batch(vb, metric, KNN_MFMA)
+    q_host = oracle.generate_uniform(args.queries, args.dim, 0xBE7C)
+    q_dev = torch.from_numpy(q_host).to(dev)  # resident in HBM before the timed region
+
+    from innr_amd.dist import _gpu_local_search
+    local = _gpu_local_search(vb, metric, KNN_MFMA)
+    gemm_ms, fallbacks, kept = [], [], 0
+
+    def step():
+        nonlocal kept
+        st = KnnStats()
+        out = sk.search(q_dev, args.k, st) if sk is not None else local(q_dev, args.k, st)
+        gemm_ms.append(st.gemm_ms)
+        fallbacks.append(st.queries_fallback)
+        kept = st.candidates_kept
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    gemm_ms.clear(); fallbacks.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, sc = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = args.queries * n_total / (dt / args.steps)
+        g_ms = float(np.mean(gemm_ms))
+        flop = 2.0 * args.queries * args.n_per_gpu * args.dim  # algorithmic flop of ONE launch (one GPU's shard)
+        achieved = flop / (g_ms * 1e-3) / 1e12
+        out = {
+            "metric": "vectors scanned/sec (batch_knn_dot f32 d=768 k=10)" if args.metric == "dot"
+                      else "vectors scanned/sec (batch_knn_cosine f32)",
+            "value": value,
+            "unit": "vectors/s",
+            "qps": args.queries / (dt / args.steps),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: i.i.d. uniform(-1,1) f32 generated on device (distribution of the reference's "
+                    "criterion benches, benches/batch.rs:11-21)",
+            "config": {
+                "workload": f"batch_knn_{args.metric} f32, {args.n_per_gpu}x{args.dim} corpus per GPU "
+                            f"({n_total} total), {args.queries}-query batch, k={args.k}",
+                "engine": "f32 MFMA GEMM + fused top-k filter + exact re-score",
+                "candidates_per_query": int(kept),
+                "queries_redone_exactly_per_step": float(np.mean(fallbacks)),
+                "parallelism": f"range-partitioned corpus x{world}, all-gather of per-shard top-k" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "gemm_filter_kernel (v_mfma_f32_32x32x2_f32)",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "kernel_ms": g_ms,
+                "algorithmic_flop_per_launch": flop,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.dim, args.k)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

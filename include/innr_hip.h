@@ -67,7 +67,9 @@ typedef struct innr_knn_stats {
 /* ---- context ------------------------------------------------------------------------------ */
 innr_status innr_ctx_create(int device, innr_ctx** out);
 void innr_ctx_destroy(innr_ctx* ctx);
-/* run on an existing HIP stream (hipStream_t as void*), e.g. torch's current stream; NULL = own stream */
+/* run on the caller's HIP stream (hipStream_t as void*), e.g. torch's current stream, so the library's kernels
+ * are ordered with the caller's own device work; NULL = the device's legacy default stream. Without this call
+ * the ctx uses a private non-blocking stream (every host-pointer entry point synchronises it before returning). */
 innr_status innr_ctx_set_stream(innr_ctx* ctx, void* hip_stream);
 innr_status innr_ctx_synchronize(innr_ctx* ctx);
 const char* innr_last_error(void);

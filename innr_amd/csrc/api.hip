@@ -64,6 +64,8 @@ struct innr_ctx {
     DevBuf counts;    // list counts
     DevBuf sel;       // selected composites [Q][KP]
     DevBuf sel_cnt;   // [Q]
+    DevBuf sel_tmp[2];     // multi-level select: [parts][Q][KP]
+    DevBuf selcnt_tmp[2];  // [parts][Q]
     DevBuf scores;    // [QB][ldN] materialised scores
     DevBuf tmp_norms; // caller-provided norms staged on device
     DevBuf flags;     // error flag + per-query fallback flags
@@ -154,10 +156,44 @@ static uint32_t pick_kp(size_t k, size_t margin) {
     return kp;
 }
 
+// Cross-producer selection: best KP per query over `nslots` lists (each <= KP entries), tree-reduced in parts of
+// kSelSlots/KP lists until one part remains. Result: c->sel [Q][KP] best-first, c->sel_cnt [Q].
+static innr_status run_select(innr_ctx* c, const uint64_t* lists, const uint32_t* counts, uint32_t nslots,
+                              uint32_t qstride, uint32_t cap, uint32_t KP, uint32_t Q) {
+    INNR_TRY(c->sel.ensure((size_t)Q * KP * sizeof(uint64_t)));
+    INNR_TRY(c->sel_cnt.ensure((size_t)Q * sizeof(uint32_t)));
+    const uint32_t spp = kSelSlots / KP;
+    int level = 0;
+    while (true) {
+        const uint32_t parts = (nslots + spp - 1) / spp;
+        uint64_t* out = c->sel.as<uint64_t>();
+        uint32_t* out_cnt = c->sel_cnt.as<uint32_t>();
+        if (parts > 1) {
+            INNR_TRY(c->sel_tmp[level & 1].ensure((size_t)parts * Q * KP * sizeof(uint64_t)));
+            INNR_TRY(c->selcnt_tmp[level & 1].ensure((size_t)parts * Q * sizeof(uint32_t)));
+            out = c->sel_tmp[level & 1].as<uint64_t>();
+            out_cnt = c->selcnt_tmp[level & 1].as<uint32_t>();
+        }
+        select_topk_kernel<<<dim3(Q, parts ? parts : 1), kSelThreads, 0, c->stream>>>(lists, counts, nslots, qstride,
+                                                                                      cap, KP, Q, out, out_cnt);
+        INNR_HIP_CHECK(hipGetLastError());
+        if (parts <= 1) return INNR_OK;
+        lists = out;
+        counts = out_cnt;
+        nslots = parts;
+        qstride = Q;
+        cap = KP;
+        ++level;
+    }
+}
+
 // ---- exact engine ---------------------------------------------------------------------------------
-template <int QB>
-static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
-                                      uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps) {
+// list capacity used by the exact engine for a given KP: 64*R with R in {6, 12, 20}
+static uint32_t exact_cap(uint32_t KP) { return KP <= 32 ? 384u : (KP <= 128 ? 768u : 1280u); }
+
+template <int QB, int R>
+static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
+                                        uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cps) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
@@ -165,20 +201,30 @@ static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ
     const uint32_t N = (uint32_t)b->N, D = (uint32_t)b->D;
     switch (metric) {
         case INNR_METRIC_DOT:
-            scan_filter_kernel<QB, false, false><<<nblocks, kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cap, cps, err);
+            scan_filter_kernel<QB, false, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         case INNR_METRIC_L2SQ:
-            scan_filter_kernel<QB, true, false><<<nblocks, kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cap, cps, err);
+            scan_filter_kernel<QB, true, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         default:
-            scan_filter_kernel<QB, false, true><<<nblocks, kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cap, cps, err);
+            scan_filter_kernel<QB, false, true, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cps, err);
             break;
     }
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
+}
+
+template <int QB>
+static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
+                                      uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps) {
+    switch (cap) {
+        case 384: return launch_scan_filter_r<QB, 6>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
+        case 768: return launch_scan_filter_r<QB, 12>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
+        default: return launch_scan_filter_r<QB, 20>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
+    }
 }
 
 // Exact kNN for queries [q0, q0+nq) (row-major on device, stride ldq): results to d_out_* at row q0.
@@ -186,10 +232,12 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
                                    size_t q0, size_t nq, size_t kout, uint64_t* d_out_idx, float* d_out_score) {
     innr_ctx* c = b->ctx;
     const uint32_t KP = pick_kp(kout, 0);
-    const uint32_t cap = (uint32_t)cand_cap((int)KP);
+    const uint32_t cap = exact_cap(KP);
     const size_t nchunks = b->ldN / kScanChunk;
-    // wave slots: enough to fill the chip (8 waves / CU) but never more than there are chunks
-    size_t nslots = std::min<size_t>(nchunks, (size_t)c->num_cus * 8);
+    // wave slots: fill the chip to the occupancy the register budget allows (HBM latency needs the waves: the
+    // single-query kernel holds 72 VGPRs = 7 waves/SIMD) but never more than there are chunks
+    const size_t waves_per_cu = nq >= 8 ? 16 : 24;
+    size_t nslots = std::min<size_t>(nchunks, (size_t)c->num_cus * waves_per_cu);
     nslots = round_up(nslots, kScanThreads / 64);
     const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
     const uint32_t nblocks = (uint32_t)(nslots / (kScanThreads / 64));
@@ -202,19 +250,15 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
     size_t done = 0;
     while (done < nq) {
         const size_t rem = nq - done;
-        const uint32_t qb = rem >= 8 ? 8 : (rem >= 4 ? 4 : (rem >= 2 ? 2 : 1));
+        const uint32_t qb = rem >= 8 ? 8 : (rem >= 4 ? 4 : 1);
         const float* q = dQ + (q0 + done) * ldq;
         const float* qn = dQn ? dQn + q0 + done : nullptr;
         switch (qb) {
             case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
             case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
-            case 2: INNR_TRY(launch_scan_filter<2>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
             default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
         }
-        select_topk_kernel<<<qb, kSelThreads, 0, c->stream>>>(c->lists.as<uint64_t>(), c->counts.as<uint32_t>(),
-                                                              (uint32_t)nslots, qb, cap, KP, c->sel.as<uint64_t>(),
-                                                              c->sel_cnt.as<uint32_t>());
-        INNR_HIP_CHECK(hipGetLastError());
+        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, qb, cap, KP, qb));
         const uint32_t total = qb * (uint32_t)kout;
         emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
             c->sel.as<uint64_t>(), KP, qb, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
@@ -321,10 +365,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     else INNR_TRY((launch_gemm<false, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
-    select_topk_kernel<<<(unsigned)Q, kSelThreads, 0, c->stream>>>(c->lists.as<uint64_t>(), c->counts.as<uint32_t>(),
-                                                                  p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
-                                                                  c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>());
-    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
+                        (uint32_t)Q));
 
     // |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
@@ -423,8 +465,9 @@ innr_status innr_ctx_create(int device, innr_ctx** out) {
 void innr_ctx_destroy(innr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
+                      &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc};
     for (DevBuf* b : bufs) b->release();
     for (auto& ev : c->ev)
@@ -438,13 +481,8 @@ innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
     INNR_TRY(bind_device(c));
     INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    if (hip_stream) {
-        c->stream = (hipStream_t)hip_stream;
-        c->own_stream = false;
-    } else {
-        INNR_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream (what torch uses unless told otherwise)
+    c->own_stream = false;
     return INNR_OK;
 }
 

@@ -88,12 +88,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_scores_kernel(const float* 
 
 // ---- fused top-k variant: exact scores -> threshold filter -> per-wave candidate lists ---------------
 // Wave `slot` owns chunks [slot*cps, (slot+1)*cps) and lists[slot][0..QB). See topk_dev.h.
-template <int QB, bool L2, bool COS>
+// R = list capacity / 64 (compile-time so only ONE compaction width is instantiated per kernel: the dynamic
+// dispatch cost 150-196 VGPRs and capped the scan at 2-3 waves/SIMD, far too few to cover HBM latency).
+template <int QB, bool L2, bool COS, int R>
 __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
     const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, const float* __restrict__ Qm, size_t ldq,
     const float* __restrict__ norms, const float* __restrict__ qnorm, uint64_t* __restrict__ lists,
-    uint32_t* __restrict__ counts, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t chunks_per_slot,
+    uint32_t* __restrict__ counts, uint32_t qstride, uint32_t KP, uint32_t chunks_per_slot,
     uint32_t* __restrict__ errflag) {
+    constexpr uint32_t cap = 64 * R;
     __shared__ uint32_t s_cnt[kScanThreads / 64][QB];
     __shared__ uint32_t s_thr[kScanThreads / 64][QB];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -131,13 +134,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 1  // one copy of the compaction code, not QB inlined copies (register pressure)
         for (int j = 0; j < QB; ++j) {
             const uint32_t c = __builtin_amdgcn_readfirstlane(
                 __hip_atomic_load(&s_cnt[w][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
             if (c > cap - kBurst) {  // wave-uniform (scalar branch)
                 uint32_t t;
-                const uint32_t keep = wave_compact_dyn(my_lists + (size_t)j * cap, c, KP, cap, &t);
+                const uint32_t keep = wave_compact<R>(my_lists + (size_t)j * cap, c, KP, &t);
                 if (lane == 0) {
                     s_cnt[w][j] = keep;
                     s_thr[w][j] = t;
@@ -147,13 +150,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
         __builtin_amdgcn_wave_barrier();
     }
     // leave at most KP entries per list (bounds the select kernel's work), then publish the counts
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < QB; ++j) {
         uint32_t c = __builtin_amdgcn_readfirstlane(
             __hip_atomic_load(&s_cnt[w][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
         if (c > KP) {
             uint32_t t;
-            c = wave_compact_dyn(my_lists + (size_t)j * cap, c, KP, cap, &t);
+            c = wave_compact<R>(my_lists + (size_t)j * cap, c, KP, &t);
         }
         if (lane == 0) counts[slot * qstride + j] = c;
     }

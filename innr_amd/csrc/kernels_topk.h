@@ -38,36 +38,46 @@ __device__ __forceinline__ int next_pow2_i(int x) {
 // One workgroup per query: best KP composites over all producer lists of that query.
 //   lists  : [nslots][qstride][cap] composites, counts : [nslots][qstride]; query q uses column `q`
 //   out    : [Q][KP] best-first, zero padded; out_cnt[q] = min(KP, total)
+//   Producers leave at most KP entries per list, so list `s` of a part owns the fixed window
+//   [s*KP, (s+1)*KP): no prefix sums, one gather, one sort. Part p (blockIdx.y) reduces the
+//   kSelSlots/KP lists [p*spp, (p+1)*spp) and writes out[(p*Q + q)*KP ..], out_cnt[p*Q + q]; the host
+//   re-launches on that output (as lists with qstride = Q, cap = KP) until one part remains.
 __global__ __launch_bounds__(kSelThreads) void select_topk_kernel(const uint64_t* __restrict__ lists,
                                                                    const uint32_t* __restrict__ counts,
                                                                    uint32_t nslots, uint32_t qstride, uint32_t cap,
-                                                                   uint32_t KP, uint64_t* __restrict__ out,
+                                                                   uint32_t KP, uint32_t Q, uint64_t* __restrict__ out,
                                                                    uint32_t* __restrict__ out_cnt) {
     __shared__ uint64_t s[kSelSlots];
-    const uint32_t q = blockIdx.x;
-    int fill = 0;  // uniform across the workgroup
-    for (uint32_t slot = 0; slot < nslots; ++slot) {
-        const uint32_t c = counts[(size_t)slot * qstride + q];
-        if (c == 0) continue;
-        if (fill + (int)c > kSelSlots) {  // window full: reduce to the best KP first
-            const int n = next_pow2_i(fill);
-            for (int i = fill + threadIdx.x; i < n; i += kSelThreads) s[i] = 0;
-            __syncthreads();
-            wg_bitonic_desc(s, n);
-            fill = fill < (int)KP ? fill : (int)KP;
+    __shared__ uint32_t s_total;
+    const uint32_t q = blockIdx.x, part = blockIdx.y;
+    const uint32_t spp = kSelSlots / KP;  // lists per part
+    const uint32_t slot0 = part * spp;
+    const uint32_t nloc = (slot0 >= nslots) ? 0u : ((nslots - slot0 < spp) ? nslots - slot0 : spp);
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    const int n = next_pow2_i((int)(nloc * KP) > 1 ? (int)(nloc * KP) : 1);
+    uint32_t mine = 0;
+    for (int e = threadIdx.x; e < n; e += kSelThreads) {
+        const uint32_t ls = (uint32_t)e / KP, i = (uint32_t)e % KP;
+        uint64_t v = 0;
+        if (ls < nloc) {
+            uint32_t c = counts[(size_t)(slot0 + ls) * qstride + q];
+            c = c < KP ? c : KP;
+            if (i < c) {
+                v = lists[((size_t)(slot0 + ls) * qstride + q) * cap + i];
+                ++mine;
+            }
         }
-        const uint64_t* src = lists + ((size_t)slot * qstride + q) * cap;
-        for (uint32_t i = threadIdx.x; i < c; i += kSelThreads) s[fill + i] = src[i];
-        fill += (int)c;
-        __syncthreads();
+        s[e] = v;
     }
-    const int n = next_pow2_i(fill > 1 ? fill : 1);
-    for (int i = fill + threadIdx.x; i < n; i += kSelThreads) s[i] = 0;
+    if (mine) atomicAdd(&s_total, mine);
     __syncthreads();
     wg_bitonic_desc(s, n);
-    const int keep = fill < (int)KP ? fill : (int)KP;
-    for (int i = threadIdx.x; i < (int)KP; i += kSelThreads) out[(size_t)q * KP + i] = (i < keep) ? s[i] : 0ull;
-    if (threadIdx.x == 0) out_cnt[q] = (uint32_t)keep;
+    const uint32_t total = s_total;
+    const uint32_t keep = total < KP ? total : KP;
+    for (uint32_t i = threadIdx.x; i < KP; i += kSelThreads)
+        out[((size_t)part * Q + q) * KP + i] = (i < keep) ? s[i] : 0ull;
+    if (threadIdx.x == 0) out_cnt[(size_t)part * Q + q] = keep;
 }
 
 // Exact engines: composites already carry the reference's exact score bits. One thread per (q, r).

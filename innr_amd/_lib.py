@@ -9,6 +9,7 @@ from __future__ import annotations
 import atexit
 import ctypes as C
 import os
+import sys
 import threading
 import weakref
 from typing import Optional
@@ -88,6 +89,26 @@ _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process. The PyTorch-ROCm wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and loads it by the name 'libamdhip64.so'; if /opt/rocm's copy is already mapped under the
+    SONAME, the loader maps torch's copy as a SECOND runtime and torch then reports "No HIP GPUs are available".
+    Mapping torch's copy first (no `import torch` needed) makes libinnr_hip.so's NEEDED libamdhip64.so.7 resolve
+    to it, whichever of the two is used first. Without torch installed this is a no-op (system ROCm is used)."""
+    if os.environ.get("INNR_HIP_SYSTEM_RUNTIME") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load() -> C.CDLL:
     """Load libinnr_hip.so (built by __graft_entry__.build() / innr_amd/csrc/Makefile). Raises if absent."""
     global _lib
@@ -98,6 +119,7 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). innr_amd has no CPU fallback.")
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = ABI drift, fail loudly

@@ -127,35 +127,93 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
 
-    if (total > 0) stage_tile(s, 0, V, ldN, (size_t)t0 * kBC, Qt, Qpad, q0, 0, w, lane);
+    // Per-lane source pointers of this wave's 6 DMA pieces (2 corpus, 4 query), advanced incrementally so the
+    // K-loop carries no 64-bit multiplies; wave-uniform LDS destinations of both stages, computed once.
+    const float* pa[2];
+    const float* pq[4];
+    uint32_t la[2][2], lq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
+        la[0][j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
+        la[1][j] = lds_addr_uniform(&s.A[1][4 * w + 2 * j][0]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pq[j] = Qt + (size_t)(4 * w + j) * Qpad + q0 + (size_t)lane * 4;
+        lq[0][j] = lds_addr_uniform(&s.B[0][4 * w + j][0]);
+        lq[1][j] = lds_addr_uniform(&s.B[1][4 * w + j][0]);
+    }
+    const size_t a_step = (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
+    const size_t a_wrap = (size_t)(Dpad - kBK) * ldN - kBC;  // subtract at a tile change: back to row 0, next tile
+    const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad;
+    uint32_t pks = 0;  // K-step index the pointers refer to
+    auto advance = [&]() {
+        if (++pks == nk) {
+            pks = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pa[j] -= a_wrap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pq[j] -= q_wrap;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pa[j] += a_step;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pq[j] += q_step;
+        }
+    };
+    if (total > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(pa[j], la[0][j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(pq[j], lq[0][j]);
+        advance();
+    }
     wait_stage_landed();
     __syncthreads();  // stage 0 visible to every wave
 
     uint32_t tile = t0, ks = 0;
     for (uint32_t step = 0; step < total; ++step) {
         const int st = step & 1;
-        // prefetch the next K-step (possibly the next tile's first) into the other stage
-        if (step + 1 < total) {
-            uint32_t ntile = tile, nks = ks + 1;
-            if (nks == nk) {
-                nks = 0;
-                ntile = tile + 1;
+        const bool has_next = step + 1 < total;  // wave-uniform
+        // 4 groups of 2 k-pairs: fragment reads, then (groups 0-2) two LDS-DMA pieces of the NEXT K-step into the
+        // other stage -- issued while the fragment reads are in flight -- then 16 MFMAs. Spreading the DMA issue
+        // keeps every non-MFMA stretch short enough to hide behind MFMAs that are already queued.
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            float4 av[2];
+            float2 bv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kp = 2 * grp + h;
+                av[h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+                bv[h] = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
             }
-            stage_tile(s, st ^ 1, V, ldN, (size_t)ntile * kBC, Qt, Qpad, q0, nks * kBK, w, lane);
+            if (has_next) {
+                if (grp == 0) {
+                    glds16(pa[0], st ? la[0][0] : la[1][0]);
+                    glds16(pa[1], st ? la[0][1] : la[1][1]);
+                } else if (grp == 1) {
+                    glds16(pq[0], st ? lq[0][0] : lq[1][0]);
+                    glds16(pq[1], st ? lq[0][1] : lq[1][1]);
+                } else if (grp == 2) {
+                    glds16(pq[2], st ? lq[0][2] : lq[1][2]);
+                    glds16(pq[3], st ? lq[0][3] : lq[1][3]);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a[4] = {av[h].x, av[h].y, av[h].z, av[h].w};
+                const float bb[2] = {bv[h].x, bv[h].y};
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bb[ct], acc[rt][ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // 8 k-pairs x (4 x 2) MFMAs on the current stage
-#pragma unroll
-        for (int kp = 0; kp < kBK / 2; ++kp) {
-            const float4 av = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
-            const float2 bv = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
-            const float a[4] = {av.x, av.y, av.z, av.w};
-            const float bb[2] = {bv.x, bv.y};
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bb[ct], acc[rt][ct], 0, 0, 0);
-        }
+        if (has_next) advance();
 
         if (ks + 1 == nk) {
             // ---------------- epilogue for corpus tile `tile` ----------------

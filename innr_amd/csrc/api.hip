@@ -64,6 +64,7 @@ struct innr_ctx {
     DevBuf counts;    // list counts
     DevBuf sel;       // selected composites [Q][KP]
     DevBuf sel_cnt;   // [Q]
+    DevBuf gthr;           // GEMM engine: global threshold slots + bounds
     DevBuf sel_tmp[2];     // multi-level select: [parts][Q][KP]
     DevBuf selcnt_tmp[2];  // [parts][Q]
     DevBuf scores;    // [QB][ldN] materialised scores
@@ -298,10 +299,15 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
     uint32_t* err = c->flags.as<uint32_t>();
-#define INNR_GEMM_LAUNCH(RR)                                                                                     \
+    // chip-wide threshold state: [Qpad][KP] slots followed by [Qpad] bounds, zeroed for every launch
+    const size_t gbytes = (p.Qpad * p.KP + p.Qpad) * sizeof(uint32_t);
+    INNR_TRY(c->gthr.ensure(gbytes));
+    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
+    uint32_t* gslots = c->gthr.as<uint32_t>();
+#define INNR_GEMM_LAUNCH(RR)                                                                                    \
     gemm_filter_kernel<COS, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                 \
         b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, p.nqt, p.tps, invn, invq, lists, counts, p.KP, \
-        err, dump, ld_dump)
+        err, gslots, gslots + p.Qpad * p.KP, dump, ld_dump)
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;
         case 512: INNR_GEMM_LAUNCH(8); break;
@@ -466,7 +472,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
+    DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc};
     for (DevBuf* b : bufs) b->release();

@@ -38,12 +38,15 @@ constexpr int kBQ = 256;   // queries per block tile
 constexpr int kBK = 16;    // K-step
 constexpr int kGemmBurst = kBC;  // most appends one tile can make to one query's list
 
+constexpr int kStages = 3;  // LDS ring: the DMA for K-step s+2 is issued during step s (two steps of cover)
+
 struct alignas(16) GemmLds {
-    alignas(16) float A[2][kBK][kBC];  // 2 x 8 KiB
-    alignas(16) float B[2][kBK][kBQ];  // 2 x 16 KiB
+    alignas(16) float A[kStages][kBK][kBC];  // 3 x 8 KiB
+    alignas(16) float B[kStages][kBK][kBQ];  // 3 x 16 KiB
     uint32_t cnt[kBQ];
     uint32_t thr[kBQ];
 };
+constexpr uint32_t kStageBytesA = kBK * kBC * 4, kStageBytesB = kBK * kBQ * 4;
 
 // One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS [M0 .. M0 + 1 KiB), linear.
 // Written as inline asm on purpose: for the builtin, hipcc (ROCm 7.2) treats every later ds_read as aliasing
@@ -69,29 +72,17 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
     return __builtin_amdgcn_readfirstlane(a);
 }
 
-// Stage one K-step (16 dimension rows) of the corpus tile and the query tile into LDS stage `st`.
-// Each wave issues 6 LDS-DMA instructions of 1 KiB: 2 for the corpus (2 rows of 512 B each) and 4 for the
-// queries (1 row of 1 KiB each). LDS destination = wave-uniform base + lane*16 (linear), source per lane.
-__device__ __forceinline__ void stage_tile(GemmLds& s, int st, const float* __restrict__ V, size_t ldN, size_t c0,
-                                           const float* __restrict__ Qt, size_t Qpad, size_t q0, uint32_t k0, int w,
-                                           int lane) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 4 * w + 2 * j;  // rows row, row+1
-        const float* g = V + (size_t)(k0 + row + (lane >> 5)) * ldN + c0 + (size_t)(lane & 31) * 4;
-        glds16(g, lds_addr_uniform(&s.A[st][row][0]));
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 4 * w + j;
-        const float* g = Qt + (size_t)(k0 + row) * Qpad + q0 + (size_t)lane * 4;
-        glds16(g, lds_addr_uniform(&s.B[st][row][0]));
-    }
-}
-
-// Every LDS-DMA this wave issued has landed (they are the only asm-issued VMEM ops; compiler-issued loads and
-// stores of the epilogue share the counter, so this also drains those: once per K-step, after the MFMAs).
-__device__ __forceinline__ void wait_stage_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Staging of one K-step (16 dimension rows of the corpus tile and of the query tile): each wave issues 6 LDS-DMA
+// instructions of 1 KiB -- 2 for the corpus (2 rows of 512 B each) and 4 for the queries (1 row of 1 KiB each).
+// LDS destination = wave-uniform base + lane*16 (linear), source address per lane.
+//
+// vmcnt counts every VMEM op of the wave in issue order (DMA, epilogue loads/stores alike).
+//   wait_all():      everything this wave issued has completed.
+//   wait_but_last(): all but the 6 youngest ops have completed. At the end of K-step s the 6 youngest are (at
+//                    least) the DMA pieces of step s+2 issued during s, so the pieces of step s+1 (issued during
+//                    s-1) are in LDS; epilogue traffic issued later only makes the wait stricter.
+__device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_but_last() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 
 // MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
 template <bool COS, int R, int MODE>
@@ -99,7 +90,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
-    float* __restrict__ dump, size_t ld_dump) {
+    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
     __shared__ GemmLds s;
     constexpr uint32_t cap = 64 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -131,18 +122,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     // K-loop carries no 64-bit multiplies; wave-uniform LDS destinations of both stages, computed once.
     const float* pa[2];
     const float* pq[4];
-    uint32_t la[2][2], lq[2][4];
+    uint32_t la[2], lq[4];  // stage-0 destinations; stage k adds k * kStageBytes{A,B}
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
-        la[0][j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
-        la[1][j] = lds_addr_uniform(&s.A[1][4 * w + 2 * j][0]);
+        la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         pq[j] = Qt + (size_t)(4 * w + j) * Qpad + q0 + (size_t)lane * 4;
-        lq[0][j] = lds_addr_uniform(&s.B[0][4 * w + j][0]);
-        lq[1][j] = lds_addr_uniform(&s.B[1][4 * w + j][0]);
+        lq[j] = lds_addr_uniform(&s.B[0][4 * w + j][0]);
     }
     const size_t a_step = (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
     const size_t a_wrap = (size_t)(Dpad - kBK) * ldN - kBC;  // subtract at a tile change: back to row 0, next tile
@@ -162,23 +151,29 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             for (int j = 0; j < 4; ++j) pq[j] += q_step;
         }
     };
-    if (total > 0) {
+    // prologue: K-steps 0 and 1 into stages 0 and 1
 #pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(pa[j], la[0][j]);
+    for (int p = 0; p < 2; ++p) {
+        if ((uint32_t)p < total) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(pq[j], lq[0][j]);
-        advance();
+            for (int j = 0; j < 2; ++j) glds16(pa[j], la[j] + p * kStageBytesA);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(pq[j], lq[j] + p * kStageBytesB);
+            advance();
+        }
     }
-    wait_stage_landed();
-    __syncthreads();  // stage 0 visible to every wave
+    wait_all();
+    __syncthreads();  // stages 0 and 1 visible to every wave
 
     uint32_t tile = t0, ks = 0;
+    uint32_t st = 0;  // stage holding the current K-step; the DMA of step+2 goes to stage (st + 2) % 3
     for (uint32_t step = 0; step < total; ++step) {
-        const int st = step & 1;
-        const bool has_next = step + 1 < total;  // wave-uniform
-        // 4 groups of 2 k-pairs: fragment reads, then (groups 0-2) two LDS-DMA pieces of the NEXT K-step into the
-        // other stage -- issued while the fragment reads are in flight -- then 16 MFMAs. Spreading the DMA issue
-        // keeps every non-MFMA stretch short enough to hide behind MFMAs that are already queued.
+        const bool has_next = step + 2 < total;  // wave-uniform: is there a K-step to prefetch?
+        const uint32_t dst = (st == 0) ? 2u : st - 1;
+        const uint32_t da = dst * kStageBytesA, dq = dst * kStageBytesB;
+        // 4 groups of 2 k-pairs: fragment reads, then (groups 0-2) two LDS-DMA pieces of K-step s+2 into the ring
+        // stage that step s-1 released -- issued while the fragment reads are in flight -- then 16 MFMAs.
+        // Spreading the DMA issue keeps every non-MFMA stretch short enough to hide behind queued MFMAs.
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             float4 av[2];
@@ -191,14 +186,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             }
             if (has_next) {
                 if (grp == 0) {
-                    glds16(pa[0], st ? la[0][0] : la[1][0]);
-                    glds16(pa[1], st ? la[0][1] : la[1][1]);
+                    glds16(pa[0], la[0] + da);
+                    glds16(pa[1], la[1] + da);
                 } else if (grp == 1) {
-                    glds16(pq[0], st ? lq[0][0] : lq[1][0]);
-                    glds16(pq[1], st ? lq[0][1] : lq[1][1]);
+                    glds16(pq[0], lq[0] + dq);
+                    glds16(pq[1], lq[1] + dq);
                 } else if (grp == 2) {
-                    glds16(pq[2], st ? lq[0][2] : lq[1][2]);
-                    glds16(pq[3], st ? lq[0][3] : lq[1][3]);
+                    glds16(pq[2], lq[2] + dq);
+                    glds16(pq[3], lq[3] + dq);
                 }
             }
 #pragma unroll
@@ -234,8 +229,22 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                         }
                 }
             } else {
-                // scale (cosine) and convert to total-order keys in place; track this lane's best per query
-                uint32_t best[2] = {0, 0};
+                // Threshold of each of this lane's two queries: the better of the list's own (KP-th best it holds)
+                // and the chip-wide bound gthr[q] (topk_dev.h, global threshold slots).
+                uint32_t thr[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const uint32_t tl = __hip_atomic_load(&s.thr[64 * w + 2 * C + ct], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const uint32_t tg = __hip_atomic_load(&gthr[q0 + 64 * w + 2 * C + ct], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                    thr[ct] = tl > tg ? tl : tg;
+                }
+                // Fast reject. For a threshold that is a non-negative float (the normal case once a list has KP
+                // entries), "some value >= thr in total order" == "max over RAW BIT PATTERNS compared as signed
+                // ints >= raw(thr)": non-negative floats (and +NaN, the greatest) order like their bits and every
+                // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
+                int32_t best[2] = {INT32_MIN, INT32_MIN};
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {  // 16 consecutive corpus rows: tb + 4*(8*gq + 4*half) + [0,16)
                     float sc[16];
@@ -255,31 +264,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt) {
                                 float v = acc[rt][ct][4 * gq + g3];
-                                if (COS) v = v * sc[4 * g3 + rt] * iq;
-                                const uint32_t o = f32_ord(v);
-                                acc[rt][ct][4 * gq + g3] = __uint_as_float(o);
-                                best[ct] = best[ct] > o ? best[ct] : o;
+                                if (COS) {
+                                    v = v * sc[4 * g3 + rt] * iq;
+                                    acc[rt][ct][4 * gq + g3] = v;
+                                }
+                                const int32_t raw = (int32_t)__float_as_uint(v);
+                                best[ct] = best[ct] > raw ? best[ct] : raw;
                             }
                     }
                 }
-                uint32_t thr[2];
-                thr[0] = __hip_atomic_load(&s.thr[64 * w + 2 * C + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                thr[1] = __hip_atomic_load(&s.thr[64 * w + 2 * C + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                const bool any_hit = (best[0] >= thr[0]) || (best[1] >= thr[1]);
-                if (__any(any_hit)) {
+                bool hit[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const bool nonneg_thr = (thr[ct] & 0x80000000u) != 0;  // ord of a non-negative float
+                    hit[ct] = !nonneg_thr || best[ct] >= (int32_t)(thr[ct] & 0x7fffffffu);
+                }
+                if (__any(hit[0] || hit[1])) {
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const int ql = 64 * w + 2 * C + ct;
                         uint64_t* lq = my_lists + (size_t)ql * cap;
-                        if (best[ct] >= thr[ct]) {
+                        if (hit[ct]) {
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                                 for (int g = 0; g < 16; ++g) {
-                                    const uint32_t o = __float_as_uint(acc[rt][ct][g]);
+                                    const uint32_t o = f32_ord(acc[rt][ct][g]);
                                     const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
-                                    if (o >= thr[ct] && i < N)
+                                    if (o >= thr[ct] && i < N) {
                                         cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
+                                        gthr_offer(gslots + (q0 + ql) * (size_t)KP, gthr + q0 + ql, KP, o, (uint32_t)i);
+                                    }
                                 }
                         }
                     }
@@ -297,6 +312,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                         if (lane == 0) {
                             s.cnt[ql] = keep;
                             s.thr[ql] = t;
+                            // a list's own KP-th best is a valid chip-wide bound too
+                            if (t > __hip_atomic_load(&gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                __hip_atomic_fetch_max(&gthr[q0 + ql], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -313,8 +331,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         } else {
             ++ks;
         }
-        wait_stage_landed();  // this wave's share of the next stage is in LDS ...
-        __syncthreads();      // ... and so is everyone else's; the stage just consumed is free to overwrite
+        // This wave's pieces of K-step s+1 (issued one step ago) are in LDS; the pieces of s+2 stay in flight.
+        if (has_next) wait_but_last();
+        else wait_all();
+        __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step
+        st = (st == 2) ? 0u : st + 1;
     }
 
     if (MODE == 0) {

@@ -45,6 +45,32 @@ __device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint3
     else atomicOr(errflag, 1u);
 }
 
+// ---- chip-wide threshold ("global threshold slots") ---------------------------------------------------
+// With S producers per query each list's own threshold only knows 1/S of the corpus seen so far, so almost
+// every tile still yields candidates. The producers therefore share, per query, KP monotone slots:
+//   slots[idx % KP] = max pref of any admitted candidate whose corpus index falls in that residue class.
+// Distinct slots were raised by distinct corpus vectors, so t = min over the KP slots certifies "at least KP
+// vectors score >= t": anything below t cannot be in the top KP, whichever producer sees it (ties pass).
+// t sits near global rank KP*ln(KP) instead of KP: a 3-4x weaker filter than the ideal one, ~S/4 times
+// stronger than a producer's own. Everything is relaxed agent-scope atomicMax / loads: a stale or lost update
+// only makes the bound weaker, never wrong. slots and gthr are zeroed before every launch (0 = "no bound").
+__device__ __forceinline__ void gthr_offer(uint32_t* slots, uint32_t* gthr_q, uint32_t KP, uint32_t pref,
+                                           uint32_t idx) {
+    uint32_t* sl = slots + (idx & (KP - 1));  // KP is a power of two
+    if (pref > __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        const uint32_t old = __hip_atomic_fetch_max(sl, pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old < pref) {  // this candidate raised its class: the certified bound may have moved
+            uint32_t mn = 0xffffffffu;
+            for (uint32_t j = 0; j < KP; ++j) {
+                const uint32_t v = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mn = mn < v ? mn : v;
+            }
+            if (mn > __hip_atomic_load(gthr_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // Compact a list of `cnt` (<= 64*R) distinct composites to its best min(cnt, KP), written back sorted
 // best-first at list[0..keep). Returns keep; *thr_pref = pref of the KP-th best (0 = "no threshold yet"
 // while fewer than KP entries exist). Rank counting: rank(e) = #entries greater than e; entries are

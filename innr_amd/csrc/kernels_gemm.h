@@ -174,16 +174,25 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         // 4 groups of 2 k-pairs: fragment reads, then (groups 0-2) two LDS-DMA pieces of K-step s+2 into the ring
         // stage that step s-1 released -- issued while the fragment reads are in flight -- then 16 MFMAs.
         // Spreading the DMA issue keeps every non-MFMA stretch short enough to hide behind queued MFMAs.
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            float4 av[2];
-            float2 bv[2];
+        // Fragments are software-pipelined one group ahead (two register sets): group g+1's LDS reads are issued
+        // before group g's MFMAs, so only the first group of a step (right after the barrier) exposes LDS latency.
+        float4 avs[2][2];
+        float2 bvs[2][2];
+        auto read_frags = [&](int grp, int set) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int kp = 2 * grp + h;
-                av[h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
-                bv[h] = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
+                avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+                bvs[set][h] = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
             }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int cur = grp & 1;
+            if (grp < 3) read_frags(grp + 1, cur ^ 1);
+            const float4(&av)[2] = avs[cur];
+            const float2(&bv)[2] = bvs[cur];
             if (has_next) {
                 if (grp == 0) {
                     glds16(pa[0], la[0] + da);
@@ -245,27 +254,28 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 // ints >= raw(thr)": non-negative floats (and +NaN, the greatest) order like their bits and every
                 // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
                 int32_t best[2] = {INT32_MIN, INT32_MIN};
+                float iq[2] = {1.0f, 1.0f};
+                if (COS) {
+                    iq[0] = invq[q0 + 64 * w + 2 * C + 0];
+                    iq[1] = invq[q0 + 64 * w + 2 * C + 1];
+                }
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {  // 16 consecutive corpus rows: tb + 4*(8*gq + 4*half) + [0,16)
-                    float sc[16];
-                    if (COS) {
-                        const float4* p = reinterpret_cast<const float4*>(invn + tb + 4 * (8 * gq + 4 * half));
+                    const float4* p = reinterpret_cast<const float4*>(invn + tb + 4 * (8 * gq + 4 * half));
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            const float4 t = p[x];
-                            sc[4 * x + 0] = t.x; sc[4 * x + 1] = t.y; sc[4 * x + 2] = t.z; sc[4 * x + 3] = t.w;
+                    for (int g3 = 0; g3 < 4; ++g3) {
+                        float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // 1/||v|| of corpus rows 4*(g3 + ...) + rt
+                        if (COS) {
+                            const float4 t = p[g3];
+                            sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
                         }
-                    }
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const float iq = COS ? invq[q0 + 64 * w + 2 * C + ct] : 1.0f;
-#pragma unroll
-                        for (int g3 = 0; g3 < 4; ++g3)
+                        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt) {
                                 float v = acc[rt][ct][4 * gq + g3];
                                 if (COS) {
-                                    v = v * sc[4 * g3 + rt] * iq;
+                                    v = v * sc[rt] * iq[ct];
                                     acc[rt][ct][4 * gq + g3] = v;
                                 }
                                 const int32_t raw = (int32_t)__float_as_uint(v);

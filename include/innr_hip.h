@@ -121,6 +121,32 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
                                int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
                                innr_knn_stats* stats);
 
+/* ---- L2 variants of the batch module (exact engine, one query) -------------------------------------- */
+/* batch_dimension_variance (batch.rs:572-592): out[D]; sequential sums in the reference's order, cached per batch */
+innr_status innr_batch_dimension_variance(innr_batch* b, float* out);
+/* batch_knn_filtered (batch.rs:820-882): mask[i] != 0 <=> predicate(i); only passing vectors are scored.
+ * *out_k = min(k, number passing); indices refer to the original batch positions. */
+innr_status innr_batch_knn_filtered(innr_batch* b, const float* q, size_t D, size_t k, const uint8_t* mask,
+                                    uint64_t* out_idx, float* out_score, size_t* out_k);
+/* batch_knn_reordered (batch.rs:621-659): distances accumulated in decreasing-variance dimension order
+ * (variance_order :599-603), then k smallest by (distance, index). */
+innr_status innr_batch_knn_reordered(innr_batch* b, const float* q, size_t D, size_t k, uint64_t* out_idx,
+                                     float* out_score, size_t* out_k);
+/* batch_l2_squared_pruning (batch.rs:320-365): every (index, squared distance) with distance not > threshold,
+ * in index order. *out_n = number of survivors; at most `cap` of them are written. */
+innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t D, float threshold, uint64_t* out_idx,
+                                          float* out_dist, size_t cap, size_t* out_n);
+
+/* ---- pairwise surface kept on the host: called per PAIR by graph indexes, so a kernel
+ * launch cannot pay for itself. Plain host functions in the reference's portable arithmetic order. ------------ */
+float innr_dot_f32(const float* a, const float* b, size_t n);    /* dense::dot_portable dense.rs:103; DistDot = -dot, distance.rs:88 */
+float innr_cosine_f32(const float* a, const float* b, size_t n); /* dense::cosine_portable dense.rs:288; DistCosine = 1 - cosine, distance.rs:76 */
+float innr_l2sq_f32(const float* a, const float* b, size_t n);   /* dense::l2_distance_squared_portable dense.rs:648; DistL2 = sqrt, distance.rs:99 */
+float innr_l1_f32(const float* a, const float* b, size_t n);     /* dense::l1_distance_portable dense.rs:550; DistL1, distance.rs:110 */
+/* maxsim / maxsim_cosine of ONE (query, document) pair (maxsim.rs:96-194, portable path :142-152); tokens packed
+ * row-major [n][dim]; cosine != 0 selects maxsim_cosine. Empty query or document -> 0.0. */
+innr_status innr_maxsim_pair(const float* q, size_t nq, const float* d, size_t nd, size_t dim, int cosine, float* out);
+
 /* ---- multi-GPU merge (range partition + all-gather of per-shard top-k) --------- */
 /* in: G shards x Q queries x kin candidates (device pointers, layout [g][q][kin], global indices);
  * out: best kout per query by (score order of `metric`, index ascending). */

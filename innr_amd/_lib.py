@@ -82,7 +82,16 @@ SIGNATURES = {
     "innr_batch_norms": (C.c_int, [_vp, _vp]),
     "innr_batch_knn": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
     "innr_batch_knn_dev": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_batch_dimension_variance": (C.c_int, [_vp, _vp]),
+    "innr_batch_knn_filtered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _szp]),
+    "innr_batch_knn_reordered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _szp]),
+    "innr_batch_l2_squared_pruning": (C.c_int, [_vp, _vp, _sz, C.c_float, _vp, _vp, _sz, _szp]),
     "innr_merge_topk_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "innr_dot_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_cosine_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_l2sq_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_l1_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_maxsim_pair": (C.c_int, [_vp, _sz, _vp, _sz, _sz, C.c_int, _f32p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -272,14 +272,48 @@ def batch_knn_multi(queries, batch: VerticalBatch, k: int, engine: int = KNN_AUT
     return knn_multi(METRIC_L2SQ, queries, batch, k, engine, stats)
 
 
-def _not_yet(name: str, where: str):
-    def f(*a, **kw):
-        raise NotImplementedError(f"{name} ({where}) has no device kernel yet in innr_amd; there is no CPU "
-                                  "fallback by design (SURVEY.md 8f 'next')")
-    f.__name__ = name
-    return f
+def batch_dimension_variance(batch: VerticalBatch) -> np.ndarray:
+    """batch.rs:572-592: per-dimension variance across all vectors (sequential sums, reference order)."""
+    out = np.empty(batch.dimension(), dtype=np.float32)
+    check(load().innr_batch_dimension_variance(batch._h, _vp(out) if out.size else None))
+    return out
 
 
-batch_knn_filtered: Callable = _not_yet("batch_knn_filtered", "batch.rs:820-882")
-batch_knn_reordered: Callable = _not_yet("batch_knn_reordered", "batch.rs:621-659")
-batch_l2_squared_pruning: Callable = _not_yet("batch_l2_squared_pruning", "batch.rs:320-365")
+def _l2_variant(fn_name: str, query, batch: VerticalBatch, k: int, *extra) -> BatchKnnResult:
+    q = _f32(query).reshape(-1)
+    _assert_dim(q, batch)
+    kk = max(min(int(k), batch.num_vectors()), 1)
+    idx = np.empty(kk, dtype=np.uint64)
+    sc = np.empty(kk, dtype=np.float32)
+    out_k = C.c_size_t(0)
+    check(getattr(load(), fn_name)(batch._h, _vp(q) if q.size else None, q.size, int(k), *extra, _vp(idx), _vp(sc),
+                                   C.byref(out_k)))
+    r = int(out_k.value)
+    return BatchKnnResult(indices=[int(i) for i in idx[:r]], scores=[float(s) for s in sc[:r]])
+
+
+def batch_knn_filtered(query, batch: VerticalBatch, k: int, predicate: Callable[[int], bool]) -> BatchKnnResult:
+    """batch.rs:820-882: kNN (squared L2) over the vectors where predicate(index) is true. Like the reference,
+    the predicate is evaluated once per index up front (batch.rs:839) into a mask; the scan runs on the GPU."""
+    mask = np.fromiter((1 if predicate(i) else 0 for i in range(batch.num_vectors())), dtype=np.uint8,
+                       count=batch.num_vectors())
+    return _l2_variant("innr_batch_knn_filtered", query, batch, k, _vp(mask) if mask.size else None)
+
+
+def batch_knn_reordered(query, batch: VerticalBatch, k: int) -> BatchKnnResult:
+    """batch.rs:621-659: exact kNN with distances accumulated in decreasing-variance dimension order."""
+    return _l2_variant("innr_batch_knn_reordered", query, batch, k)
+
+
+def batch_l2_squared_pruning(query, batch: VerticalBatch, threshold: float):
+    """batch.rs:320-365: [(index, squared_distance)] of the vectors within `threshold`, in index order."""
+    q = _f32(query).reshape(-1)
+    _assert_dim(q, batch)
+    n = batch.num_vectors()
+    idx = np.empty(max(n, 1), dtype=np.uint64)
+    ds = np.empty(max(n, 1), dtype=np.float32)
+    out_n = C.c_size_t(0)
+    check(load().innr_batch_l2_squared_pruning(batch._h, _vp(q) if q.size else None, q.size, C.c_float(threshold),
+                                               _vp(idx), _vp(ds), n, C.byref(out_n)))
+    r = int(out_n.value)
+    return [(int(idx[i]), float(ds[i])) for i in range(r)]

@@ -12,6 +12,7 @@
 #include "kernels_scan.h"
 #include "kernels_topk.h"
 #include "kernels_gemm.h"
+#include "kernels_ext.h"
 
 namespace innr {
 
@@ -85,6 +86,7 @@ struct innr_batch {
     bool norms_ready = false;
     float max_norm = 0.0f;
     uint64_t index_base = 0;
+    std::vector<float> dimvar;  // batch_dimension_variance, computed once (batch.rs:572)
 };
 
 namespace innr {
@@ -192,9 +194,16 @@ static innr_status run_select(innr_ctx* c, const uint64_t* lists, const uint32_t
 // list capacity used by the exact engine for a given KP: 64*R with R in {6, 12, 20}
 static uint32_t exact_cap(uint32_t KP) { return KP <= 32 ? 384u : (KP <= 128 ? 768u : 1280u); }
 
+// optional extras of the L2 variants (device pointers; both null for the plain scans)
+struct ScanExt {
+    const uint8_t* mask = nullptr;    // [ldN] predicate bytes (batch_knn_filtered)
+    const uint32_t* order = nullptr;  // [D] dimension order (batch_knn_reordered)
+};
+
 template <int QB, int R>
 static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
-                                        uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cps) {
+                                        uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cps,
+                                        const ScanExt& ext) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
@@ -206,8 +215,13 @@ static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* 
                 b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         case INNR_METRIC_L2SQ:
-            scan_filter_kernel<QB, true, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
+            if (ext.mask || ext.order)
+                scan_filter_kernel<QB, true, false, R, true><<<nblocks, kScanThreads, 0, c->stream>>>(
+                    b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err, ext.mask,
+                    ext.order);
+            else
+                scan_filter_kernel<QB, true, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+                    b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         default:
             scan_filter_kernel<QB, false, true, R><<<nblocks, kScanThreads, 0, c->stream>>>(
@@ -220,17 +234,19 @@ static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* 
 
 template <int QB>
 static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
-                                      uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps) {
+                                      uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps,
+                                      const ScanExt& ext) {
     switch (cap) {
-        case 384: return launch_scan_filter_r<QB, 6>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
-        case 768: return launch_scan_filter_r<QB, 12>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
-        default: return launch_scan_filter_r<QB, 20>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps);
+        case 384: return launch_scan_filter_r<QB, 6>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
+        case 768: return launch_scan_filter_r<QB, 12>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
+        default: return launch_scan_filter_r<QB, 20>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
     }
 }
 
 // Exact kNN for queries [q0, q0+nq) (row-major on device, stride ldq): results to d_out_* at row q0.
 static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
-                                   size_t q0, size_t nq, size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+                                   size_t q0, size_t nq, size_t kout, uint64_t* d_out_idx, float* d_out_score,
+                                   const ScanExt& ext = ScanExt()) {
     innr_ctx* c = b->ctx;
     const uint32_t KP = pick_kp(kout, 0);
     const uint32_t cap = exact_cap(KP);
@@ -255,9 +271,9 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
         const float* q = dQ + (q0 + done) * ldq;
         const float* qn = dQn ? dQn + q0 + done : nullptr;
         switch (qb) {
-            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
-            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
-            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps)); break;
+            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
+            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
+            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
         }
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, qb, cap, KP, qb));
         const uint32_t total = qb * (uint32_t)kout;
@@ -813,6 +829,146 @@ innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size
         INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return INNR_OK;
+}
+
+// ---- L2 variants (exact engine) ------------------------------------------------------------------------
+innr_status innr_batch_dimension_variance(innr_batch* b, float* out) {
+    if (!b || (!out && b->D)) return INNR_E_BAD_ARG;
+    if (b->D == 0) return INNR_OK;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    if (b->dimvar.empty()) {
+        INNR_TRY(c->misc.ensure(b->D * sizeof(float)));
+        dimension_variance_kernel<<<(unsigned)((b->D + 63) / 64), 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N,
+                                                                                    (uint32_t)b->D, c->misc.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+        b->dimvar.resize(b->D);
+        INNR_HIP_CHECK(hipMemcpyAsync(b->dimvar.data(), c->misc.p, b->D * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    memcpy(out, b->dimvar.data(), b->D * sizeof(float));
+    return INNR_OK;
+}
+
+// shared driver of batch_knn_filtered / batch_knn_reordered: one query, L2, optional mask / dimension order
+static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k, const uint8_t* mask,
+                              const uint32_t* order_host, uint64_t* out_idx, float* out_score, size_t* out_k) {
+    if (!b || !out_k) return INNR_E_BAD_ARG;
+    if (D != b->D) {  // batch.rs:622, 829
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    *out_k = 0;
+    if (b->N == 0 || k == 0) return INNR_OK;  // batch.rs:624-629, 831-836
+    const size_t kout = std::min(k, b->N);
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_TRY(c->q_row.ensure(std::max<size_t>(D, 1) * sizeof(float)));
+    INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    ScanExt ext;
+    if (mask) {
+        INNR_TRY(c->tmp_norms.ensure(b->ldN));  // reused as the predicate byte array, zero padded
+        INNR_HIP_CHECK(hipMemsetAsync(c->tmp_norms.p, 0, b->ldN, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(c->tmp_norms.p, mask, b->N, hipMemcpyHostToDevice, c->stream));
+        ext.mask = c->tmp_norms.as<uint8_t>();
+    }
+    if (order_host) {
+        INNR_TRY(c->misc.ensure(std::max<size_t>(D, 1) * sizeof(uint32_t)));
+        INNR_HIP_CHECK(hipMemcpyAsync(c->misc.p, order_host, D * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        ext.order = c->misc.as<uint32_t>();
+    }
+    INNR_TRY(knn_exact_range(b, INNR_METRIC_L2SQ, c->q_row.as<float>(), D, nullptr, 0, 1, kout, c->out_idx.as<uint64_t>(),
+                             c->out_score.as<float>(), ext));
+    uint32_t have = 0;  // filtered: fewer than k vectors may pass (k = k.min(num_passing), batch.rs:849)
+    INNR_HIP_CHECK(hipMemcpyAsync(&have, c->sel_cnt.p, sizeof(have), hipMemcpyDeviceToHost, c->stream));
+    INNR_TRY(check_errflag(c));
+    const size_t n = std::min<size_t>(kout, have);
+    if (n) {
+        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    *out_k = n;
+    return INNR_OK;
+}
+
+innr_status innr_batch_knn_filtered(innr_batch* b, const float* q, size_t D, size_t k, const uint8_t* mask,
+                                    uint64_t* out_idx, float* out_score, size_t* out_k) {
+    if (b && b->N && !mask) {
+        set_error("mask is null");
+        return INNR_E_BAD_ARG;
+    }
+    return knn_l2_ext(b, q, D, k, mask, nullptr, out_idx, out_score, out_k);
+}
+
+innr_status innr_batch_knn_reordered(innr_batch* b, const float* q, size_t D, size_t k, uint64_t* out_idx,
+                                     float* out_score, size_t* out_k) {
+    if (!b) return INNR_E_BAD_ARG;
+    std::vector<uint32_t> order(b->D);
+    if (b->D && b->N && k && D == b->D) {
+        std::vector<float> var(b->D);
+        INNR_TRY(innr_batch_dimension_variance(b, var.data()));
+        for (size_t d = 0; d < b->D; ++d) order[d] = (uint32_t)d;
+        // variance_order (batch.rs:599-603): stable sort of the dimensions by variance, descending total_cmp
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t a, uint32_t c2) { return f32_ord(var[a]) > f32_ord(var[c2]); });
+    }
+    return knn_l2_ext(b, q, D, k, nullptr, b->D ? order.data() : nullptr, out_idx, out_score, out_k);
+}
+
+innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t D, float threshold, uint64_t* out_idx,
+                                          float* out_dist, size_t cap, size_t* out_n) {
+    if (!b || !out_n) return INNR_E_BAD_ARG;
+    if (D != b->D) {  // batch.rs:325
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    *out_n = 0;
+    if (b->N == 0) return INNR_OK;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    // full exact distances on the device (bit-identical to batch_l2_squared) ...
+    const size_t ldq = round_up(D ? D : 1, 4);
+    INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
+    INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const size_t nchunks = b->ldN / kScanChunk;
+    const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+    scan_scores_kernel<1, true, false><<<blocks, kScanThreads, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, c->q_row.as<float>(),
+                                                                               ldq, nullptr, nullptr, c->scores.as<float>(), b->ldN);
+    INNR_HIP_CHECK(hipGetLastError());
+    // ... then the survivors, in index order
+    const uint32_t nb = (uint32_t)((b->N + 255) / 256);
+    INNR_TRY(c->counts.ensure(((size_t)nb * 2 + 1) * sizeof(uint32_t)));
+    uint32_t* cnt = c->counts.as<uint32_t>();
+    uint32_t* off = cnt + nb;
+    uint32_t* total = off + nb;
+    prune_count_kernel<<<nb, 256, 0, c->stream>>>(c->scores.as<float>(), (uint32_t)b->N, threshold, cnt);
+    exclusive_scan_kernel<<<1, 1024, 0, c->stream>>>(cnt, nb, off, total);
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t n = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&n, total, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *out_n = n;  // survivors found; the caller's buffers hold min(n, cap) of them
+    const size_t m = std::min<size_t>(n, cap);
+    if (m == 0) return INNR_OK;
+    if (!out_idx || !out_dist) return INNR_E_BAD_ARG;
+    INNR_TRY(c->out_idx.ensure(m * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(m * sizeof(float)));
+    prune_scatter_kernel<<<nb, 256, 0, c->stream>>>(c->scores.as<float>(), (uint32_t)b->N, threshold, off, b->index_base,
+                                                   c->out_idx.as<uint64_t>(), c->out_score.as<float>(), (uint32_t)m);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, m * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipMemcpyAsync(out_dist, c->out_score.p, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
     return INNR_OK;
 }
 

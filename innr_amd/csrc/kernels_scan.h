@@ -18,15 +18,18 @@ constexpr int kScanThreads = 256;          // 4 waves
 constexpr int kScanChunk = 64 * 4;         // vectors per wave step (64 lanes x float4)
 
 // acc[j][c] for QB queries x 4 vectors starting at column `col` (col % 4 == 0, col + 3 < ldN).
-template <int QB, bool L2>
+// ORD: walk the dimensions in the order given by `order[0..D)` (batch_knn_reordered, batch.rs:640-648).
+template <int QB, bool L2, bool ORD = false>
 __device__ __forceinline__ void scan_accumulate(const float* __restrict__ V, size_t ldN, uint32_t D, size_t col,
-                                                const float* __restrict__ Qm, size_t ldq, float (&acc)[QB][4]) {
+                                                const float* __restrict__ Qm, size_t ldq, float (&acc)[QB][4],
+                                                const uint32_t* __restrict__ order = nullptr) {
 #pragma unroll
     for (int j = 0; j < QB; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
     const float4* p = reinterpret_cast<const float4*>(V + col);
     const size_t stride = ldN / 4;
 #pragma unroll 8
-    for (uint32_t d = 0; d < D; ++d) {
+    for (uint32_t t = 0; t < D; ++t) {
+        const uint32_t d = (ORD && order) ? order[t] : t;
         const float4 v = p[(size_t)d * stride];
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
@@ -90,12 +93,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_scores_kernel(const float* 
 // Wave `slot` owns chunks [slot*cps, (slot+1)*cps) and lists[slot][0..QB). See topk_dev.h.
 // R = list capacity / 64 (compile-time so only ONE compaction width is instantiated per kernel: the dynamic
 // dispatch cost 150-196 VGPRs and capped the scan at 2-3 waves/SIMD, far too few to cover HBM latency).
-template <int QB, bool L2, bool COS, int R>
+// EXT: the L2 variants of the reference -- `mask` (batch_knn_filtered's predicate evaluated per index,
+// batch.rs:839: only passing vectors are scored/admitted) and `order` (batch_knn_reordered's dimension order).
+template <int QB, bool L2, bool COS, int R, bool EXT = false>
 __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
     const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, const float* __restrict__ Qm, size_t ldq,
     const float* __restrict__ norms, const float* __restrict__ qnorm, uint64_t* __restrict__ lists,
     uint32_t* __restrict__ counts, uint32_t qstride, uint32_t KP, uint32_t chunks_per_slot,
-    uint32_t* __restrict__ errflag) {
+    uint32_t* __restrict__ errflag, const uint8_t* __restrict__ mask = nullptr,
+    const uint32_t* __restrict__ order = nullptr) {
     constexpr uint32_t cap = 64 * R;
     __shared__ uint32_t s_cnt[kScanThreads / 64][QB];
     __shared__ uint32_t s_thr[kScanThreads / 64][QB];
@@ -113,7 +119,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
     for (size_t ch = ch0; ch < ch1; ++ch) {
         const size_t col = ch * kScanChunk + (size_t)lane * 4;
         float acc[QB][4];
-        scan_accumulate<QB, L2>(V, ldN, D, col, Qm, ldq, acc);
+        scan_accumulate<QB, L2, EXT>(V, ldN, D, col, Qm, ldq, acc, order);
+        uint32_t pass4 = 0x01010101u;  // per-vector predicate bytes (EXT: from the caller's mask)
+        if (EXT && mask) pass4 = (col + 3 < N) ? *reinterpret_cast<const uint32_t*>(mask + col)
+                                               : ((col < N ? mask[col] : 0u) | ((col + 1 < N ? mask[col + 1] : 0u) << 8) |
+                                                  ((col + 2 < N ? mask[col + 2] : 0u) << 16));
         float vn[4] = {0, 0, 0, 0};
         if (COS) {
             const float4 t = *reinterpret_cast<const float4*>(norms + col);
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
                 float s = acc[j][c];
                 if (COS) s = cosine_epilogue(s, qn, vn[c]);
                 const uint32_t pref = score_pref<L2>(s);
-                if (i < N && pref >= thr)
+                if (i < N && pref >= thr && ((pass4 >> (8 * c)) & 0xffu))
                     cand_append(my_lists + (size_t)j * cap, &s_cnt[w][j], cap, cand_make(pref, (uint32_t)i), errflag);
             }
         }

@@ -1,0 +1,56 @@
+"""Host-side mirror of innr's `distance` module (reference: src/distance.rs:66-143).
+
+`Distance<T>::eval(a, b) -> f32`, smaller = more similar. These are PAIRWISE metrics that an external index
+(hnsw_rs via anndists, distance.rs:148-193) calls hundreds of times per query on single pairs, so they stay on
+the host: plain functions of libinnr_hip.so in the reference's portable arithmetic order.
+The batched scans are what runs on the GPU (innr_amd.batch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from ._lib import InnrPanic, load
+
+
+def _pair(fn_name: str, what: str, a, b) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+    if a.size != b.size:  # assert_eq!(a.len(), b.len(), "innr::dot: slice length mismatch ...") dense.rs:57-63
+        raise InnrPanic(f"innr::{what}: slice length mismatch ({a.size} vs {b.size})")
+    return float(getattr(load(), fn_name)(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), a.size))
+
+
+def dot(a, b) -> float: return _pair("innr_dot_f32", "dot", a, b)
+def cosine(a, b) -> float: return _pair("innr_cosine_f32", "cosine", a, b)
+def l2_distance_squared(a, b) -> float: return _pair("innr_l2sq_f32", "l2_distance_squared", a, b)
+def l2_distance(a, b) -> float: return float(np.sqrt(np.float32(l2_distance_squared(a, b))))
+def l1_distance(a, b) -> float: return _pair("innr_l1_f32", "l1_distance", a, b)
+
+
+class Distance:
+    """distance.rs:66-69"""
+    def eval(self, a, b) -> float:  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class DistCosine(Distance):
+    """distance.rs:73-80: 1 - cosine_similarity, range [0, 2]."""
+    def eval(self, a, b) -> float: return float(np.float32(1.0) - np.float32(cosine(a, b)))
+
+
+class DistDot(Distance):
+    """distance.rs:85-92: negated dot product."""
+    def eval(self, a, b) -> float: return -dot(a, b)
+
+
+class DistL2(Distance):
+    """distance.rs:96-103: Euclidean distance."""
+    def eval(self, a, b) -> float: return l2_distance(a, b)
+
+
+class DistL1(Distance):
+    """distance.rs:107-114: Manhattan distance."""
+    def eval(self, a, b) -> float: return l1_distance(a, b)

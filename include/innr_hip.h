@@ -121,6 +121,32 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
                                int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
                                innr_knn_stats* stats);
 
+/* ---- scalar-quantised corpus: asymmetric f32 query x u8 codes (src/scalar.rs) ------------------------------ */
+/* A &[QuantizedU8] (scalar.rs:171-174: N separately allocated Vec<u8>) becomes one device-resident code array.
+ * codes: row-major packed [N*D] (document i's bytes at codes + i*D); alpha/offset = the collection's
+ * QuantizationParams (scalar.rs:44-49). The result is an innr_batch that only the *_u8 entry points accept. */
+innr_status innr_batch_upload_u8(innr_ctx* ctx, const uint8_t* codes, size_t N, size_t D, float alpha, float offset,
+                                 innr_batch** out);
+/* synthetic codes on the device: row i = quantize_u8(uniform row (row0+i) of stream `seed`, params) (scalar.rs:212) */
+innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t seed, uint64_t row0, float alpha,
+                                   float offset, innr_batch** out);
+/* codes back to the host, dimension-major out[d*N + i] */
+innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out);
+/* asymmetric_dot_u8_precomputed for every document (scalar.rs:284-300; the map inside batch_knn_u8 :384-388):
+ * out[i] = (alpha/255)*mixed_dot(q, codes_i) + offset*sum(q), bit-identical to the portable path. */
+innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float* out);
+/* batch_knn_u8 (scalar.rs:370-393) for Q queries: top-k by asymmetric dot, descending, ties -> lower index.
+ * Same conventions as innr_batch_knn (k' = min(k,N); empty corpus or k == 0 -> *out_k = 0 before any check). */
+innr_status innr_batch_knn_u8(innr_batch* b, const float* queries, size_t Q, size_t D, size_t k, int engine,
+                              uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats);
+innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t Q, size_t D, size_t k, int engine,
+                                  uint64_t* d_out_idx, float* d_out_score, size_t* out_k, innr_knn_stats* stats);
+/* quantize_u8 (scalar.rs:212-225) on the host (one-time ingest step): out[i] =
+ * clamp(round((v[i]-offset)*255/alpha), 0, 255), round = half away from zero */
+void innr_quantize_u8(const float* values, size_t n, float alpha, float offset, uint8_t* out);
+/* mixed_dot_u8_f32 for one pair (scalar.rs:314-358, portable loop), host function like the other pairwise ones */
+float innr_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n);
+
 /* ---- L2 variants of the batch module (exact engine, one query) -------------------------------------- */
 /* batch_dimension_variance (batch.rs:572-592): out[D]; sequential sums in the reference's order, cached per batch */
 innr_status innr_batch_dimension_variance(innr_batch* b, float* out);

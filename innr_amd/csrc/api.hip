@@ -13,6 +13,7 @@
 #include "kernels_topk.h"
 #include "kernels_gemm.h"
 #include "kernels_ext.h"
+#include "kernels_u8.h"
 
 namespace innr {
 
@@ -87,6 +88,9 @@ struct innr_batch {
     float max_norm = 0.0f;
     uint64_t index_base = 0;
     std::vector<float> dimvar;  // batch_dimension_variance, computed once (batch.rs:572)
+    // scalar-quantised corpus (scalar.rs): codes C8[d*ldN + i] instead of V, with the collection's params
+    uint8_t* C8 = nullptr;
+    float alpha = 1.0f, offset = 0.0f;
 };
 
 namespace innr {
@@ -308,7 +312,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
     return p;
 }
 
-template <bool COS, int MODE>
+template <int KIND, int MODE>
 static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt, const float* invn, const float* invq,
                                float* dump, size_t ld_dump) {
     innr_ctx* c = b->ctx;
@@ -321,9 +325,10 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
 #define INNR_GEMM_LAUNCH(RR)                                                                                    \
-    gemm_filter_kernel<COS, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                 \
-        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, p.nqt, p.tps, invn, invq, lists, counts, p.KP, \
-        err, gslots, gslots + p.Qpad * p.KP, dump, ld_dump)
+    gemm_filter_kernel<KIND, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                \
+        KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
+        p.nqt, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
+        ld_dump)
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;
         case 512: INNR_GEMM_LAUNCH(8); break;
@@ -383,8 +388,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
 
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (cos) INNR_TRY((launch_gemm<true, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0)));
-    else INNR_TRY((launch_gemm<false, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0)));
+    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
@@ -613,6 +618,7 @@ void innr_batch_free(innr_batch* b) {
         (void)hipStreamSynchronize(b->ctx->stream);
     }
     if (b->V) (void)hipFree(b->V);
+    if (b->C8) (void)hipFree(b->C8);
     if (b->norms) (void)hipFree(b->norms);
     if (b->invn) (void)hipFree(b->invn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
@@ -635,6 +641,10 @@ innr_status innrdbg_last_selection(innr_batch* b, size_t Q, size_t KP, uint64_t*
 // Test hook (not part of the ABI, not declared in include/innr_hip.h): dense approximate score matrix of the
 // GEMM engine, out[q*N + i], to check the MFMA operand/accumulator layout against the oracle.
 innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, float* out) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || !queries || !out || D != b->D || Q == 0 || b->N == 0) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
@@ -648,9 +658,9 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
-    if (cos) INNR_TRY((launch_gemm<true, 1>(b, p, c->q_kmajor.as<float>(), b->invn, c->misc.as<float>(),
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 1>(b, p, c->q_kmajor.as<float>(), b->invn, c->misc.as<float>(),
                                             c->scores.as<float>(), b->ldN)));
-    else INNR_TRY((launch_gemm<false, 1>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
+    else INNR_TRY((launch_gemm<kGemmDot, 1>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float),
                                     b->N * sizeof(float), Q, hipMemcpyDeviceToHost, c->stream));
     INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -661,6 +671,10 @@ size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
 size_t innr_batch_dimension(const innr_batch* b) { return b ? b->D : 0; }
 
 innr_status innr_batch_download_colmajor(innr_batch* b, float* out) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
     if (b->N == 0 || b->D == 0) return INNR_OK;
     INNR_TRY(bind_device(b->ctx));
@@ -678,6 +692,10 @@ innr_status innr_batch_set_index_base(innr_batch* b, uint64_t base) {
 
 // ---- scans ---------------------------------------------------------------------------------------------
 innr_status innr_batch_norms(innr_batch* b, float* out) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || (!out && b->N)) return INNR_E_BAD_ARG;
     if (b->N == 0) return INNR_OK;
     INNR_TRY(bind_device(b->ctx));
@@ -688,6 +706,10 @@ innr_status innr_batch_norms(innr_batch* b, float* out) {
 }
 
 innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t D, const float* norms, float* out) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || !metric_ok(metric)) {
         set_error("bad batch/metric");
         return INNR_E_BAD_ARG;
@@ -747,6 +769,10 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
 innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D, size_t k,
                                int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
                                innr_knn_stats* stats) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!b || !metric_ok(metric) || !out_k) {
         set_error("bad batch/metric/out_k");
@@ -806,6 +832,10 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
 
 innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, size_t k, int engine,
                            uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!b || !out_k) return INNR_E_BAD_ARG;
     if (D != b->D) {
@@ -832,8 +862,314 @@ innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size
     return INNR_OK;
 }
 
+}  // extern "C"  (the u8 section has templates and static helpers; its entry points get C linkage from the header)
+
+// ---- scalar-quantised corpus (scalar.rs) -----------------------------------------------------------------
+static innr_status alloc_batch_u8(innr_ctx* ctx, size_t N, size_t D, float alpha, float offset, innr_batch** out) {
+    if (!ctx || !out) return INNR_E_BAD_ARG;
+    if (N >= 0xFFFFFFFFull - 1024 || D > 65535) {
+        set_error("u8 corpus shard too large (N=%zu, D=%zu)", N, D);
+        return INNR_E_UNSUPPORTED;
+    }
+    INNR_TRY(bind_device(ctx));
+    innr_batch* b = new (std::nothrow) innr_batch();
+    if (!b) return INNR_E_OOM;
+    b->ctx = ctx;
+    b->N = N;
+    b->D = D;
+    b->ldN = round_up(N ? N : 1, 1024);
+    b->Dpad = round_up(D ? D : 1, 32);
+    b->alpha = alpha;
+    b->offset = offset;
+    const size_t bytes = b->ldN * b->Dpad;
+    hipError_t e = hipMalloc((void**)&b->C8, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(b->C8, 0, bytes, ctx->stream);
+    if (e != hipSuccess) {
+        set_error("u8 corpus allocation (%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        innr_batch_free(b);
+        return INNR_E_OOM;
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_upload_u8(innr_ctx* ctx, const uint8_t* codes, size_t N, size_t D, float alpha, float offset,
+                                 innr_batch** out) {
+    if (!codes && N * D) return INNR_E_BAD_ARG;
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch_u8(ctx, N, D, alpha, offset, &b));
+    if (N && D) {
+        const size_t blk = std::min(N, std::max<size_t>(1, (256ull << 20) / D));
+        uint8_t* stage = nullptr;
+        hipError_t e = hipMalloc((void**)&stage, blk * D);
+        for (size_t i0 = 0; i0 < N && e == hipSuccess; i0 += blk) {
+            const size_t n = std::min(blk, N - i0);
+            e = hipMemcpyAsync(stage, codes + i0 * D, n * D, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) break;
+            dim3 grid((unsigned)((n + 31) / 32), (unsigned)((D + 31) / 32));
+            transpose_rows_u8_kernel<<<grid, 256, 0, ctx->stream>>>(stage, (uint32_t)n, (uint32_t)D, b->C8, b->ldN, i0);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        if (stage) (void)hipFree(stage);
+        if (e != hipSuccess) {
+            set_error("u8 upload failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t seed, uint64_t row0, float alpha,
+                                   float offset, innr_batch** out) {
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch_u8(ctx, N, D, alpha, offset, &b));
+    if (N && D) {
+        dim3 grid((unsigned)((b->ldN / 16 + 255) / 256), (unsigned)D);
+        generate_u8_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(b->C8, b->ldN, (uint32_t)N, (uint32_t)D, seed, row0, offset,
+                                                              255.0f / alpha);  // scalar.rs:213 inv_alpha
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("u8 generate failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out) {
+    if (!b || !b->C8 || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
+    if (b->N == 0 || b->D == 0) return INNR_OK;
+    INNR_TRY(bind_device(b->ctx));
+    INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N, b->C8, b->ldN, b->N, b->D, hipMemcpyDeviceToHost, b->ctx->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return INNR_OK;
+}
+
+static innr_status u8_check(innr_batch* b, size_t D) {
+    if (!b || !b->C8) {
+        set_error("not a u8 batch");
+        return INNR_E_BAD_ARG;
+    }
+    if (D != b->D) {  // asymmetric_dot_u8_precomputed: "dimension mismatch" scalar.rs:290
+        set_error("asymmetric_dot_u8_precomputed: dimension mismatch (%zu vs %zu)", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    return INNR_OK;
+}
+
+// every document's asymmetric score for one query (the map inside batch_knn_u8, scalar.rs:384-388)
+innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float* out) {
+    INNR_TRY(u8_check(b, D));
+    if (b->N == 0) return INNR_OK;
+    if (!out || (!q && D)) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const size_t ldq = round_up(D ? D : 1, 4);
+    INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(2 * sizeof(float)));
+    INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    float* qsum = c->q_norm.as<float>();
+    query_sums_kernel<<<1, 64, 0, c->stream>>>(c->q_row.as<float>(), 1, (uint32_t)D, ldq, qsum, qsum + 1);
+    const size_t nchunks = b->ldN / kU8Chunk;
+    const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+    scan_u8_scores_kernel<1><<<blocks, 256, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)D, c->q_row.as<float>(), ldq, qsum,
+                                                            b->alpha / 255.0f, b->offset, c->scores.as<float>(), b->ldN);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipMemcpyAsync(out, c->scores.p, b->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return INNR_OK;
+}
+
+template <int QB>
+static innr_status launch_scan_u8(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, uint32_t nblocks,
+                                  uint32_t KP, uint32_t cap, uint32_t cps) {
+    innr_ctx* c = b->ctx;
+    const float a255 = b->alpha / 255.0f;  // scalar.rs:299 (params.alpha / 255.0), f32
+#define INNR_U8_LAUNCH(RR)                                                                                          \
+    scan_u8_filter_kernel<QB, RR><<<nblocks, 256, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->N, (uint32_t)b->D, dQ, ldq, \
+                                                                  qsum, a255, b->offset, c->lists.as<uint64_t>(),     \
+                                                                  c->counts.as<uint32_t>(), QB, KP, cps,              \
+                                                                  c->flags.as<uint32_t>())
+    switch (cap) {
+        case 384: INNR_U8_LAUNCH(6); break;
+        case 768: INNR_U8_LAUNCH(12); break;
+        default: INNR_U8_LAUNCH(20); break;
+    }
+#undef INNR_U8_LAUNCH
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// exact engine for queries [q0, q0+nq): qsum[] precomputed on device for all queries
+static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, size_t q0, size_t nq,
+                                      size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+    innr_ctx* c = b->ctx;
+    const uint32_t KP = pick_kp(kout, 0);
+    const uint32_t cap = exact_cap(KP);
+    const size_t nchunks = b->ldN / kU8Chunk;
+    size_t nslots = std::min<size_t>(nchunks, (size_t)c->num_cus * 16);
+    nslots = round_up(nslots, 4);
+    const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
+    const uint32_t nblocks = (uint32_t)(nslots / 4);
+    INNR_TRY(c->lists.ensure(nslots * 4 * cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure(nslots * 4 * sizeof(uint32_t)));
+    size_t done = 0;
+    while (done < nq) {
+        const uint32_t qb = (nq - done) >= 4 ? 4 : 1;
+        const float* q = dQ + (q0 + done) * ldq;
+        const float* qs = qsum + q0 + done;
+        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps));
+        else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps));
+        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, qb, cap, KP, qb));
+        const uint32_t total = qb * (uint32_t)kout;
+        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, qb, (uint32_t)kout, false,
+                                                                        b->index_base, d_out_idx + (q0 + done) * kout,
+                                                                        d_out_score + (q0 + done) * kout);
+        INNR_HIP_CHECK(hipGetLastError());
+        done += qb;
+    }
+    return INNR_OK;
+}
+
+// GEMM engine on a u8 corpus ("path B": codes widened to f32 in registers, f32 MFMA), same structure as knn_mfma
+static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t kout, const float* qsum, const float* qnorm,
+                               uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
+                               float* gemm_ms) {
+    innr_ctx* c = b->ctx;
+    const GemmPlan p = plan_gemm(b, Q, kout);
+    INNR_TRY(c->q_kmajor.ensure(b->Dpad * p.Qpad * sizeof(float)));
+    INNR_TRY(c->misc.ensure(p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
+    dim3 grid((unsigned)(p.Qpad / 32), (unsigned)(b->Dpad / 32));
+    transpose_queries_kernel<<<grid, 256, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, c->q_kmajor.as<float>(), p.Qpad,
+                                                          (uint32_t)b->Dpad);
+    INNR_HIP_CHECK(hipGetLastError());
+    float* oq = c->misc.as<float>();  // offset * sum(q) per query (0 for the padding queries)
+    scale_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(qsum, b->offset, p.Qpad, Q, oq);
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + p.Qpad * sizeof(float));
+    INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY((launch_gemm<kGemmU8, 0>(b, p, c->q_kmajor.as<float>(), nullptr, oq, nullptr, 0)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
+                        (uint32_t)Q));
+    const float a255 = b->alpha / 255.0f;
+    // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||, with ||c|| <= 255 sqrt(D)
+    const float err_scale = 1.05f * fabsf(a255) * (2.0f * (float)b->D + 12.0f) * 5.9604645e-08f * 255.0f * sqrtf((float)b->D);
+#define INNR_RESCORE_U8(RKV)                                                                                          \
+    rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
+                                                              c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
+                                                              (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
+                                                              d_out_score, fallback)
+    if (p.KP <= 64) INNR_RESCORE_U8(1);
+    else if (p.KP <= 128) INNR_RESCORE_U8(2);
+    else INNR_RESCORE_U8(4);
+#undef INNR_RESCORE_U8
+    INNR_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> fb(Q);
+    INNR_HIP_CHECK(hipMemcpyAsync(fb.data(), fallback, Q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
+    uint32_t nf = 0;
+    for (size_t q = 0; q < Q; ++q) {
+        if (!fb[q]) continue;
+        ++nf;
+        INNR_TRY(knn_u8_exact_range(b, dQ, b->D, qsum, q, 1, kout, d_out_idx, d_out_score));
+    }
+    *nfallback = nf;
+    *kept = p.KP;
+    return INNR_OK;
+}
+
+innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t Q, size_t D, size_t k, int engine,
+                                  uint64_t* d_out_idx, float* d_out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!out_k) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    if (b && b->C8 && (b->N == 0 || k == 0)) return INNR_OK;  // scalar.rs:376-378: checked before any dimension assert
+    INNR_TRY(u8_check(b, D));
+    if (Q == 0) return INNR_OK;
+    const size_t kout = std::min(k, b->N);  // scalar.rs:381
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    INNR_TRY(c->q_norm.ensure(2 * round_up(Q, kBQ) * sizeof(float)));
+    float* qsum = c->q_norm.as<float>();
+    float* qnorm = qsum + round_up(Q, kBQ);
+    query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
+    INNR_HIP_CHECK(hipGetLastError());
+    if (engine == INNR_KNN_AUTO) engine = Q >= 16 ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    uint32_t nfallback = 0, kept = pick_kp(kout, 0);
+    float gemm_ms = 0.0f;
+    if (engine == INNR_KNN_MFMA) {
+        INNR_TRY(knn_u8_mfma(b, d_queries, Q, kout, qsum, qnorm, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
+    } else {
+        INNR_TRY(knn_u8_exact_range(b, d_queries, D, qsum, 0, Q, kout, d_out_idx, d_out_score));
+    }
+    INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    INNR_TRY(check_errflag(c));
+    *out_k = kout;
+    if (stats) {
+        stats->engine = engine;
+        stats->queries_fallback = nfallback;
+        stats->candidates_kept = kept;
+        stats->gemm_ms = gemm_ms;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
+    }
+    return INNR_OK;
+}
+
+innr_status innr_batch_knn_u8(innr_batch* b, const float* queries, size_t Q, size_t D, size_t k, int engine,
+                              uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!b || !b->C8 || !out_k) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    if (b->N == 0 || k == 0) return INNR_OK;
+    INNR_TRY(u8_check(b, D));
+    if (Q == 0) return INNR_OK;
+    if (!queries && D) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const size_t kout = std::min(k, b->N);
+    INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
+    INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
+    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_TRY(innr_batch_knn_u8_dev(b, c->q_row.as<float>(), Q, D, k, engine, c->out_idx.as<uint64_t>(),
+                                   c->out_score.as<float>(), out_k, stats));
+    if (*out_k) {
+        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return INNR_OK;
+}
+
+extern "C" {
+
 // ---- L2 variants (exact engine) ------------------------------------------------------------------------
 innr_status innr_batch_dimension_variance(innr_batch* b, float* out) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || (!out && b->D)) return INNR_E_BAD_ARG;
     if (b->D == 0) return INNR_OK;
     innr_ctx* c = b->ctx;
@@ -854,6 +1190,10 @@ innr_status innr_batch_dimension_variance(innr_batch* b, float* out) {
 // shared driver of batch_knn_filtered / batch_knn_reordered: one query, L2, optional mask / dimension order
 static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k, const uint8_t* mask,
                               const uint32_t* order_host, uint64_t* out_idx, float* out_score, size_t* out_k) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || !out_k) return INNR_E_BAD_ARG;
     if (D != b->D) {  // batch.rs:622, 829
         set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
@@ -926,6 +1266,10 @@ innr_status innr_batch_knn_reordered(innr_batch* b, const float* q, size_t D, si
 
 innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t D, float threshold, uint64_t* out_idx,
                                           float* out_dist, size_t cap, size_t* out_n) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
     if (!b || !out_n) return INNR_E_BAD_ARG;
     if (D != b->D) {  // batch.rs:325
         set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);

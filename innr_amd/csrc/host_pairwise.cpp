@@ -5,6 +5,7 @@
 // (dense.rs:103-125, 288-346, 648-675, 550-572). Compiled with -ffp-contract=off like the rest of the library.
 #include <math.h>
 #include <stddef.h>
+#include <stdint.h>
 
 #include "../../include/innr_hip.h"
 
@@ -86,6 +87,23 @@ float innr_dot_f32(const float* a, const float* b, size_t n) { return dot_portab
 float innr_cosine_f32(const float* a, const float* b, size_t n) { return cosine_portable(a, b, n); }
 float innr_l2sq_f32(const float* a, const float* b, size_t n) { return l2sq_portable(a, b, n); }
 float innr_l1_f32(const float* a, const float* b, size_t n) { return l1_portable(a, b, n); }
+
+// quantize_u8 (scalar.rs:212-225): one-time ingest on the host; f32::round = half away from zero = roundf,
+// `as u8` saturates and maps NaN to 0.
+void innr_quantize_u8(const float* values, size_t n, float alpha, float offset, uint8_t* out) {
+    const float inv_alpha = 255.0f / alpha;
+    for (size_t i = 0; i < n; ++i) {
+        const float r = roundf((values[i] - offset) * inv_alpha);
+        out[i] = (r != r) ? 0 : (r < 0.0f ? 0 : (r > 255.0f ? 255 : (uint8_t)r));
+    }
+}
+
+// mixed_dot_u8_f32 (scalar.rs:314-358, portable loop): sum of a[i] * (b[i] as f32), folded from -0.0
+float innr_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n) {
+    float s = -0.0f;
+    for (size_t i = 0; i < n; ++i) s += a[i] * (float)b[i];
+    return s;
+}
 
 // maxsim / maxsim_cosine for ONE (query, document) pair, tokens packed row-major [n][dim] (maxsim.rs:142-152,
 // 168-194): sum over query tokens (folded from -0.0 like <f32 as Sum>::sum) of the max over document tokens

@@ -84,13 +84,28 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_but_last() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 
+__device__ __forceinline__ void wait_but_last5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+__device__ __forceinline__ void wait_but_last4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+
+enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2 };
+
+// KIND kGemmDot: score = q.v            (batch_knn_dot)
+//      kGemmCos: score = q.v * invn[i] * invq[j]   (approximate cosine; exact one in the re-score)
+//      kGemmU8 : the corpus is u8 codes C[d*ldN + i] (scalar.rs): a tile stage is 16 x 128 BYTES (2 DMA pieces per
+//                block instead of 8), fragments are widened u8 -> f32 in registers (v_cvt_f32_ubyte0..3: one
+//                ds_read_b32 feeds the four row tiles) and score = scale * (q.c) + invq[j]   (invq = offset*sum(q)):
+//                "path B" of SURVEY.md -- the f32 MFMA pipe, a quarter of the corpus bytes.
 // MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
-template <bool COS, int R, int MODE>
+template <int KIND, int R, int MODE>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
-    const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
-    uint32_t nqt, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq,
+    const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
+    uint32_t nqt, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
     uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
+    constexpr bool COS = KIND == kGemmCos;
+    constexpr bool U8 = KIND == kGemmU8;
+    const float* V = static_cast<const float*>(Vraw);
+    const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
     __shared__ GemmLds s;
     constexpr uint32_t cap = 64 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -123,18 +138,28 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const float* pa[2];
     const float* pq[4];
     uint32_t la[2], lq[4];  // stage-0 destinations; stage k adds k * kStageBytes{A,B}
+    // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each), issued by waves 0 and 1 (pa[0] only)
+    const bool a_issuer = !U8 || __builtin_amdgcn_readfirstlane(w) < 2;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
-        la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
+        if (U8) {
+            pa[j] = reinterpret_cast<const float*>(C8 + (size_t)(8 * (w & 1) + (lane >> 3)) * ldN + (size_t)t0 * kBC +
+                                                   (size_t)(lane & 7) * 16);
+            la[j] = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (w & 1));
+        } else {
+            pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
+            la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         pq[j] = Qt + (size_t)(4 * w + j) * Qpad + q0 + (size_t)lane * 4;
         lq[j] = lds_addr_uniform(&s.B[0][4 * w + j][0]);
     }
-    const size_t a_step = (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
-    const size_t a_wrap = (size_t)(Dpad - kBK) * ldN - kBC;  // subtract at a tile change: back to row 0, next tile
+    // pointer strides in floats (pa is a float* also for u8: byte strides are multiples of 4)
+    const size_t a_step = U8 ? (size_t)kBK * ldN / 4 : (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
+    // subtract at a tile change: back to row 0, next tile
+    const size_t a_wrap = U8 ? ((size_t)(Dpad - kBK) * ldN - kBC) / 4 : (size_t)(Dpad - kBK) * ldN - kBC;
     const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad;
     uint32_t pks = 0;  // K-step index the pointers refer to
     auto advance = [&]() {
@@ -151,12 +176,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             for (int j = 0; j < 4; ++j) pq[j] += q_step;
         }
     };
+    auto issue_a = [&](uint32_t stage_off) {
+        if (U8) {
+            if (a_issuer) glds16(pa[0], la[0] + stage_off);
+        } else {
+            glds16(pa[0], la[0] + stage_off);
+            glds16(pa[1], la[1] + stage_off);
+        }
+    };
     // prologue: K-steps 0 and 1 into stages 0 and 1
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if ((uint32_t)p < total) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(pa[j], la[j] + p * kStageBytesA);
+            issue_a(p * kStageBytesA);
 #pragma unroll
             for (int j = 0; j < 4; ++j) glds16(pq[j], lq[j] + p * kStageBytesB);
             advance();
@@ -182,7 +214,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int kp = 2 * grp + h;
-                avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+                if (U8) {  // 4 codes (rows 4r..4r+3 of dimension k) in one dword; widened to f32 right before the MFMAs
+                    const uint8_t* a8 = reinterpret_cast<const uint8_t*>(&s.A[st][0][0]);
+                    avs[set][h].x = __uint_as_float(
+                        *reinterpret_cast<const uint32_t*>(a8 + (2 * kp + (lane >> 5)) * kBC + 4 * (lane & 31)));
+                } else {
+                    avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+                }
                 bvs[set][h] = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
             }
         };
@@ -191,12 +229,21 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         for (int grp = 0; grp < 4; ++grp) {
             const int cur = grp & 1;
             if (grp < 3) read_frags(grp + 1, cur ^ 1);
-            const float4(&av)[2] = avs[cur];
+            float4 av[2] = {avs[cur][0], avs[cur][1]};
             const float2(&bv)[2] = bvs[cur];
+            if (U8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t c4 = __float_as_uint(avs[cur][h].x);
+                    av[h].x = (float)(c4 & 0xffu);
+                    av[h].y = (float)((c4 >> 8) & 0xffu);
+                    av[h].z = (float)((c4 >> 16) & 0xffu);
+                    av[h].w = (float)(c4 >> 24);
+                }
+            }
             if (has_next) {
                 if (grp == 0) {
-                    glds16(pa[0], la[0] + da);
-                    glds16(pa[1], la[1] + da);
+                    issue_a(da);
                 } else if (grp == 1) {
                     glds16(pq[0], lq[0] + dq);
                     glds16(pq[1], lq[1] + dq);
@@ -234,6 +281,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                             const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
                             float v = acc[rt][ct][g];
                             if (COS) v = v * invn[i] * invq[q];
+                            if (U8) v = v * scale + invq[q];
                             dump[q * ld_dump + i] = v;
                         }
                 }
@@ -255,7 +303,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
                 int32_t best[2] = {INT32_MIN, INT32_MIN};
                 float iq[2] = {1.0f, 1.0f};
-                if (COS) {
+                if (COS || U8) {  // COS: 1/||q||; U8: offset * sum(q)
                     iq[0] = invq[q0 + 64 * w + 2 * C + 0];
                     iq[1] = invq[q0 + 64 * w + 2 * C + 1];
                 }
@@ -276,6 +324,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                                 float v = acc[rt][ct][4 * gq + g3];
                                 if (COS) {
                                     v = v * sc[rt] * iq[ct];
+                                    acc[rt][ct][4 * gq + g3] = v;
+                                }
+                                if (U8) {
+                                    v = v * scale + iq[ct];
                                     acc[rt][ct][4 * gq + g3] = v;
                                 }
                                 const int32_t raw = (int32_t)__float_as_uint(v);
@@ -342,8 +394,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             ++ks;
         }
         // This wave's pieces of K-step s+1 (issued one step ago) are in LDS; the pieces of s+2 stay in flight.
-        if (has_next) wait_but_last();
-        else wait_all();
+        if (!has_next) wait_all();
+        else if (!U8) wait_but_last();     // 6 pieces per wave per step
+        else if (a_issuer) wait_but_last5();  // u8: waves 0-1 issue 1 + 4 pieces,
+        else wait_but_last4();                //     waves 2-3 issue 4
         __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step
         st = (st == 2) ? 0u : st + 1;
     }

@@ -147,6 +147,26 @@ void innr_quantize_u8(const float* values, size_t n, float alpha, float offset, 
 /* mixed_dot_u8_f32 for one pair (scalar.rs:314-358, portable loop), host function like the other pairwise ones */
 float innr_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n);
 
+/* ---- maxsim over a document corpus (src/maxsim.rs:96-194; caller shape examples/maxsim_colbert.rs:159-193) ---- */
+typedef struct innr_docs innr_docs; /* device-resident token embeddings of `docs` documents, T tokens x dim each */
+/* tokens: [docs*T*dim] row-major (document, token, dim); doc_len[docs] = valid tokens per document (<= T) or NULL */
+innr_status innr_maxsim_upload(innr_ctx* ctx, const float* tokens, const uint32_t* doc_len, size_t docs, size_t T,
+                               size_t dim, innr_docs** out);
+/* synthetic corpus on the device: token (doc,t) = normalised uniform row (row0 + doc*T + t) of stream `seed`
+ * (generate_normalized, examples/maxsim_colbert.rs:212-228, on the uniform generator) */
+innr_status innr_maxsim_generate(innr_ctx* ctx, size_t docs, size_t T, size_t dim, uint64_t seed, uint64_t row0,
+                                 innr_docs** out);
+void innr_docs_free(innr_docs* d);
+size_t innr_docs_count(const innr_docs* d);
+innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base);
+/* maxsim(query, doc_i) (cosine == 0) or maxsim_cosine (cosine != 0) for EVERY document: out[docs], bit-identical
+ * to the portable path (dot_portable / cosine_portable order). qtok: [Tq*dim]. Empty query/document -> 0.0. */
+innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, float* out);
+/* the k best documents by that score, descending, ties -> lower document index (a stable sort of the scores, as
+ * the reference example does). stats->gemm_ms = device time of the scan. */
+innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
+                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats);
+
 /* ---- L2 variants of the batch module (exact engine, one query) -------------------------------------- */
 /* batch_dimension_variance (batch.rs:572-592): out[D]; sequential sums in the reference's order, cached per batch */
 innr_status innr_batch_dimension_variance(innr_batch* b, float* out);

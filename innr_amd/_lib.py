@@ -90,6 +90,13 @@ SIGNATURES = {
     "innr_batch_knn_u8_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
     "innr_quantize_u8": (None, [_vp, _sz, C.c_float, C.c_float, _vp]),
     "innr_mixed_dot_u8_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_maxsim_upload": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
+    "innr_maxsim_generate": (C.c_int, [_vp, _sz, _sz, _sz, C.c_uint64, C.c_uint64, C.POINTER(_vp)]),
+    "innr_docs_free": (None, [_vp]),
+    "innr_docs_count": (_sz, [_vp]),
+    "innr_docs_set_index_base": (C.c_int, [_vp, C.c_uint64]),
+    "innr_maxsim_scores": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp]),
+    "innr_maxsim_topk": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _szp, C.POINTER(KnnStats)]),
     "innr_batch_dimension_variance": (C.c_int, [_vp, _vp]),
     "innr_batch_knn_filtered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _szp]),
     "innr_batch_knn_reordered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _szp]),

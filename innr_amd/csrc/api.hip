@@ -14,6 +14,7 @@
 #include "kernels_gemm.h"
 #include "kernels_ext.h"
 #include "kernels_u8.h"
+#include "kernels_maxsim.h"
 
 namespace innr {
 
@@ -1158,6 +1159,236 @@ innr_status innr_batch_knn_u8(innr_batch* b, const float* queries, size_t Q, siz
         INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return INNR_OK;
+}
+
+// ---- maxsim over a document corpus (maxsim.rs) -------------------------------------------------------------
+struct innr_docs {
+    innr_ctx* ctx = nullptr;
+    size_t ndocs = 0, T = 0, dim = 0;
+    float* tok = nullptr;          // [ndocs][T][dim]
+    uint32_t* doc_len = nullptr;   // [ndocs] or null (every document has T tokens)
+    uint64_t index_base = 0;
+};
+
+static innr_status alloc_docs(innr_ctx* ctx, size_t ndocs, size_t T, size_t dim, innr_docs** out) {
+    if (!ctx || !out) return INNR_E_BAD_ARG;
+    if (ndocs >= 0xFFFFFFFFull || dim > 1024 || T > 65535) {
+        set_error("maxsim corpus limits: docs < 2^32, dim <= 1024, T <= 65535 (got %zu, %zu, %zu)", ndocs, dim, T);
+        return INNR_E_UNSUPPORTED;
+    }
+    INNR_TRY(bind_device(ctx));
+    innr_docs* d = new (std::nothrow) innr_docs();
+    if (!d) return INNR_E_OOM;
+    d->ctx = ctx;
+    d->ndocs = ndocs;
+    d->T = T;
+    d->dim = dim;
+    const size_t bytes = std::max<size_t>(ndocs * T * dim, 1) * sizeof(float);
+    hipError_t e = hipMalloc((void**)&d->tok, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for document tokens failed: %s", bytes, hipGetErrorString(e));
+        delete d;
+        return INNR_E_OOM;
+    }
+    *out = d;
+    return INNR_OK;
+}
+
+innr_status innr_maxsim_upload(innr_ctx* ctx, const float* tokens, const uint32_t* doc_len, size_t ndocs, size_t T,
+                               size_t dim, innr_docs** out) {
+    if (!tokens && ndocs * T * dim) return INNR_E_BAD_ARG;
+    innr_docs* d = nullptr;
+    INNR_TRY(alloc_docs(ctx, ndocs, T, dim, &d));
+    hipError_t e = hipSuccess;
+    if (ndocs * T * dim) e = hipMemcpy(d->tok, tokens, ndocs * T * dim * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && doc_len && ndocs) {
+        e = hipMalloc((void**)&d->doc_len, ndocs * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(d->doc_len, doc_len, ndocs * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        set_error("maxsim upload failed: %s", hipGetErrorString(e));
+        innr_docs_free(d);
+        return INNR_E_HIP;
+    }
+    *out = d;
+    return INNR_OK;
+}
+
+innr_status innr_maxsim_generate(innr_ctx* ctx, size_t ndocs, size_t T, size_t dim, uint64_t seed, uint64_t row0,
+                                 innr_docs** out) {
+    innr_docs* d = nullptr;
+    INNR_TRY(alloc_docs(ctx, ndocs, T, dim, &d));
+    const size_t ntok = ndocs * T;
+    if (ntok && dim) {
+        generate_tokens_kernel<<<(unsigned)((ntok + 255) / 256), 256, 0, ctx->stream>>>(d->tok, ntok, (uint32_t)dim, seed, row0);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("maxsim generate failed: %s", hipGetErrorString(e));
+            innr_docs_free(d);
+            return INNR_E_HIP;
+        }
+    }
+    *out = d;
+    return INNR_OK;
+}
+
+void innr_docs_free(innr_docs* d) {
+    if (!d) return;
+    if (d->ctx) {
+        (void)hipSetDevice(d->ctx->device);
+        (void)hipStreamSynchronize(d->ctx->stream);
+    }
+    if (d->tok) (void)hipFree(d->tok);
+    if (d->doc_len) (void)hipFree(d->doc_len);
+    delete d;
+}
+
+size_t innr_docs_count(const innr_docs* d) { return d ? d->ndocs : 0; }
+
+innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base) {
+    if (!d) return INNR_E_BAD_ARG;
+    d->index_base = base;
+    return INNR_OK;
+}
+
+// scores of every document into c->scores (device); q tokens uploaded from the host
+static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim) {
+    innr_ctx* c = d->ctx;
+    if (dim != d->dim) {  // maxsim.rs:103-110
+        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
+        return INNR_E_DIM_MISMATCH;
+    }
+    INNR_TRY(c->scores.ensure(std::max<size_t>(d->ndocs, 1) * sizeof(float)));
+    float* out = c->scores.as<float>();
+    if (Tq == 0 || d->T == 0 || d->ndocs == 0) {  // maxsim.rs:97-99: empty query or empty documents -> 0.0
+        INNR_HIP_CHECK(hipMemsetAsync(out, 0, std::max<size_t>(d->ndocs, 1) * sizeof(float), c->stream));
+        return INNR_OK;
+    }
+    // query tokens zero-padded to a multiple of kMsQ so every pass can read a full block of tokens
+    const size_t Tq_pad = round_up(Tq, kMsQ);
+    INNR_TRY(c->q_row.ensure(Tq_pad * dim * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(Tq_pad * sizeof(float)));
+    INNR_HIP_CHECK(hipMemsetAsync(c->q_row.p, 0, Tq_pad * dim * sizeof(float), c->stream));
+    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, qtok, Tq * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (cosine) {
+        query_token_sq_kernel<<<(unsigned)((Tq_pad + 63) / 64), 64, 0, c->stream>>>(c->q_row.as<float>(), (uint32_t)Tq_pad,
+                                                                                   (uint32_t)dim, c->q_norm.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    uint32_t Tp = 1;
+    while (Tp < d->T && Tp < 64) Tp <<= 1;
+    const uint32_t docs_per_wave = 64 / Tp;
+    const size_t nwaves_needed = (d->ndocs + docs_per_wave - 1) / docs_per_wave;
+    const unsigned blocks = (unsigned)std::min<size_t>((nwaves_needed + 3) / 4, (size_t)c->num_cus * 2);
+    // query tokens per pass: as many as fit 64 KB of LDS (32 up to dim 508, 16 up to 1020, 8 up to 2044)
+    const uint32_t qstride = maxsim_qstride((uint32_t)dim);
+    size_t per_pass = kMsQ;
+    while (per_pass > 8 && per_pass * qstride * sizeof(float) > 64 * 1024) per_pass /= 2;
+    if (per_pass * qstride * sizeof(float) > 64 * 1024) {
+        set_error("maxsim: token dimension %zu not supported (max 2044)", dim);
+        return INNR_E_UNSUPPORTED;
+    }
+    for (size_t p0 = 0; p0 < Tq; p0 += per_pass) {
+        const uint32_t nq = (uint32_t)std::min<size_t>(per_pass, Tq - p0);
+        const float* qp = c->q_row.as<float>() + p0 * dim;
+        const float* aa = c->q_norm.as<float>() + p0;
+#define INNR_MS_LAUNCH(COSV, NQV)                                                                                       \
+    do {                                                                                                                \
+        if (d->T > 64)                                                                                                  \
+            maxsim_scan_kernel<COSV, NQV, true><<<blocks, kMsThreads, (size_t)NQV * qstride * sizeof(float), c->stream>>>( \
+                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, nq, COSV ? aa : nullptr,  \
+                out, out, p0 == 0);                                                                                     \
+        else                                                                                                            \
+            maxsim_scan_kernel<COSV, NQV, false><<<blocks, kMsThreads, (size_t)NQV * qstride * sizeof(float), c->stream>>>( \
+                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, nq, COSV ? aa : nullptr,  \
+                out, out, p0 == 0);                                                                                     \
+    } while (0)
+        if (cosine) {
+            if (nq <= 8) INNR_MS_LAUNCH(true, 8); else if (nq <= 16) INNR_MS_LAUNCH(true, 16); else INNR_MS_LAUNCH(true, 32);
+        } else {
+            if (nq <= 8) INNR_MS_LAUNCH(false, 8); else if (nq <= 16) INNR_MS_LAUNCH(false, 16); else INNR_MS_LAUNCH(false, 32);
+        }
+#undef INNR_MS_LAUNCH
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    return INNR_OK;
+}
+
+innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, float* out) {
+    if (!d || (!out && d->ndocs) || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
+    INNR_TRY(bind_device(d->ctx));
+    INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
+    if (d->ndocs) {
+        INNR_HIP_CHECK(hipMemcpyAsync(out, d->ctx->scores.p, d->ndocs * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+    }
+    return INNR_OK;
+}
+
+innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
+                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!d || !out_k || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    innr_ctx* c = d->ctx;
+    INNR_TRY(bind_device(c));
+    if (dim != d->dim && Tq && d->T) {
+        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
+        return INNR_E_DIM_MISMATCH;
+    }
+    if (d->ndocs == 0 || k == 0) return INNR_OK;
+    const size_t kout = std::min(k, d->ndocs);
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    // exact top-k of the dense score array (stable order: score desc, doc index asc -- the caller's sort in the
+    // reference example, examples/maxsim_colbert.rs:186-187)
+    const uint32_t KP = pick_kp(kout, 0), cap = exact_cap(KP);
+    const size_t nchunks = (d->ndocs + 255) / 256;
+    size_t nslots = round_up(std::min<size_t>(nchunks, (size_t)c->num_cus * 8), 4);
+    const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
+    INNR_TRY(c->lists.ensure(nslots * cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure(nslots * sizeof(uint32_t)));
+    const unsigned nb = (unsigned)(nslots / 4);
+    uint64_t* lists = c->lists.as<uint64_t>();
+    uint32_t* counts = c->counts.as<uint32_t>();
+    uint32_t* err = c->flags.as<uint32_t>();
+    const float* sc = c->scores.as<float>();
+    switch (cap) {
+        case 384: dense_filter_kernel<6><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
+        case 768: dense_filter_kernel<12><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
+        default: dense_filter_kernel<20><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
+    }
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(run_select(c, lists, counts, (uint32_t)nslots, 1, cap, KP, 1));
+    INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
+    emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, 1, (uint32_t)kout, false,
+                                                                              d->index_base, c->out_idx.as<uint64_t>(),
+                                                                              c->out_score.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    INNR_TRY(check_errflag(c));
+    INNR_HIP_CHECK(hipMemcpyAsync(out_doc, c->out_idx.p, kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *out_k = kout;
+    if (stats) {
+        stats->engine = INNR_KNN_EXACT;
+        stats->candidates_kept = KP;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) stats->gemm_ms = ms;  // the scan kernel(s)
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     return INNR_OK;
 }

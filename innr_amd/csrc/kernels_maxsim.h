@@ -1,0 +1,287 @@
+// kernels_maxsim.h -- ColBERT-style late interaction over a document corpus: maxsim / maxsim_cosine
+// (src/maxsim.rs:96-194) for ONE query against EVERY document, exact.
+//
+// Reference per document: sum_i max_j dot(q_i, d_j)   (portable path maxsim.rs:142-152 -> dense::dot_portable,
+// dense.rs:103-125: four strided accumulators, ((s0+s1)+s2)+s3, then a sequential tail; max = f32::max folded
+// from -inf (ignores NaN); sum folded from -0.0 in query-token order). The caller loops over documents and sorts
+// (examples/maxsim_colbert.rs:171-187); here one launch scores the whole corpus and a second selects the top-k.
+//
+// Roofline: HBM, 4*docs*T*dim bytes per query (C4: 32.8 GB); arithmetic intensity 2*Tq/4 = 16 flop/B at Tq = 32,
+// i.e. the reference-order VALU formulation (mul and add as separate roundings: 2 VALU ops per MAC) needs
+// ~1.2x the time HBM does. So this kernel keeps the reference's arithmetic bit for bit -- no approximate pass,
+// no re-score, no proof -- and still sits within ~30 % of the memory roof.
+//
+// Mapping: document tokens stay in their natural layout tok[(doc*T + t)*dim + d]. One lane owns one document
+// token (a wave = 64/Tp documents, Tp = T rounded up to a power of two <= 64) and keeps the 4 x Tq accumulators
+// of dot_portable in registers; the query tokens are wave-uniform scalar loads. Each lane streams its own 512-B
+// token row in 128-B bursts (8 x dwordx4 in flight: a burst is one cache line, fetched once).
+#pragma once
+
+#include "common.h"
+
+namespace innr {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMsThreads = 256;
+constexpr int kMsQ = 32;       // query tokens per pass (4 accumulators each = 128 VGPRs)
+constexpr int kMsBurst = 8;    // float4 chunks per lane per burst (128 B)
+
+__device__ __forceinline__ float wave_max_seg(float v, int seg) {  // fmaxf over aligned groups of `seg` lanes
+    for (int off = seg >> 1; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// COS: maxsim_cosine (maxsim.rs:168-194 -> dense::cosine_portable dense.rs:288-346): per pair
+//   ab/(sqrt(aa)*sqrt(bb)) if aa > eps^2 and bb > eps^2 else 0, with aa, bb accumulated in the same 4-way order.
+// partial_in / partial_out: running totals when the query has more than kMsQ tokens (passes in token order).
+// NQ (8/16/32) = query tokens per pass, a compile-time bound so the hot loop has no per-token branch. The query
+// buffer is zero-padded to NQ tokens; padded tokens are computed and ignored (only qi < nq enter the sum).
+//
+// Query operands. Every lane needs every query value q[qi][d] as a wave-uniform multiplier. Three ways were
+// measured on 100K docs x 64 x 128, Tq = 32:
+//   * LDS broadcast reads (ds_read_b128 per (qi, chunk)): 32 reads per chunk per wave keep the CU's one LDS pipe
+//     as busy as the VALU -- 4.3 ms;
+//   * scalar loads (wave-uniform global reads -> s_load_dwordx4): hipcc serialises {s_load, wait, 8 VALU} and
+//     at 100+ SGPRs cannot keep loads in flight -- 3.2 ms;
+//   * THIS: the query sits in LDS (rows padded to an odd number of 16-B units: conflict-free), each lane reads
+//     ONE float4 per two chunks -- lane l holds q[l & 31][chunk c + (l >> 5)] -- and v_readlane_b32 broadcasts a
+//     value into an SGPR right before its mul. 1.5 VALU-issue slots per MAC-half instead of 1, but no memory
+//     pipe on the critical path at all.
+// q[0..3] = lane `src` of v.x, v.y, v.z, v.w as wave-uniform values (SGPRs). Inline asm because the builtin
+// (__builtin_amdgcn_readlane) is hoisted freely by the compiler, see maxsim_burst.
+__device__ __forceinline__ void bcast4(float (&q)[4], const float4& v, int src) {
+    asm volatile(
+        "v_readlane_b32 %0, %4, %8\n\tv_readlane_b32 %1, %5, %8\n\tv_readlane_b32 %2, %6, %8\n\tv_readlane_b32 %3, %7, %8"
+        : "=s"(q[0]), "=s"(q[1]), "=s"(q[2]), "=s"(q[3])
+        : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"(src));
+}
+
+template <int NQ, bool FULL>
+__device__ __forceinline__ void maxsim_burst(f32x2 (&acc)[NQ][2], float (&bb)[4], const float* __restrict__ row,
+                                             const float* s_q, uint32_t qstride, uint32_t c0, uint32_t chunks,
+                                             int lane, bool cos) {
+    float4 dv[kMsBurst];
+#pragma unroll
+    for (int b = 0; b < kMsBurst; ++b)
+        if (FULL || c0 + b < chunks) {
+#ifdef INNR_MS_PROBE_NOLOAD  // tools/maxsim_probe.hip: arithmetic only
+            dv[b] = make_float4((float)(c0 + b), (float)lane, 1.0f, 2.0f);
+#else
+            dv[b] = *reinterpret_cast<const float4*>(row + 4 * (c0 + b));
+#endif
+        }
+    float4 vq[kMsBurst / 2];
+    const uint32_t qrow = ((uint32_t)lane & 31u) % (uint32_t)NQ;
+#pragma unroll
+    for (int p = 0; p < kMsBurst / 2; ++p) {
+        const uint32_t c = c0 + 2 * p + ((uint32_t)lane >> 5);
+        vq[p] = (FULL || c < chunks) ? *reinterpret_cast<const float4*>(s_q + qrow * qstride + 4 * c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int b = 0; b < kMsBurst; ++b) {
+        if (FULL || c0 + b < chunks) {  // wave-uniform
+            if (cos) {
+                bb[0] = ex::mad2(bb[0], dv[b].x, dv[b].x);
+                bb[1] = ex::mad2(bb[1], dv[b].y, dv[b].y);
+                bb[2] = ex::mad2(bb[2], dv[b].z, dv[b].z);
+                bb[3] = ex::mad2(bb[3], dv[b].w, dv[b].w);
+            }
+            const float4 v = vq[b >> 1];
+            // software pipeline, pinned with sched_barrier: the 4 v_readlane of token qi+1 issue next to the 4
+            // mul/add of token qi (gfx950 wants 2 wait states between a VALU SGPR write and its VALU read). Left
+            // to itself the scheduler hoists all 128 readlanes of a chunk, runs out of SGPRs and spills them.
+            float qn[4], qc[4];
+            const int src0 = (b & 1) * 32;
+            bcast4(qc, v, src0);
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+#ifdef INNR_MS_PROBE_NOMATH  // tools/maxsim_probe.hip: loads only (one token's arithmetic keeps them live)
+                if (qi > 0) break;
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (qi + 1 < NQ) bcast4(qn, v, src0 + qi + 1);
+                // two packed pairs: fl(acc + fl(q*d)) per element (v_pk_mul_f32 + v_pk_add_f32; -ffp-contract=off)
+                const f32x2 q01 = {qc[0], qc[1]}, q23 = {qc[2], qc[3]};
+                const f32x2 d01 = {dv[b].x, dv[b].y}, d23 = {dv[b].z, dv[b].w};
+                f32x2 t01 = q01 * d01, t23 = q23 * d23;
+                asm volatile("" : "+v"(t01), "+v"(t23));  // both products before either sum: no back-to-back dependency
+                acc[qi][0] = acc[qi][0] + t01;
+                acc[qi][1] = acc[qi][1] + t23;
+                // pin the results here (pure arithmetic would otherwise sink below all the broadcasts)
+                asm volatile("" : "+v"(acc[qi][0]), "+v"(acc[qi][1]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qc[e] = qn[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// LDS row stride (floats) of the staged query: >= 4*chunks, an ODD number of 16-B units so that the 32 rows a
+// ds_read_b128 touches fall in distinct bank groups.
+__host__ __device__ inline uint32_t maxsim_qstride(uint32_t dim) { return 4u * ((dim / 4u) | 1u); }
+
+// MULTI: documents longer than 64 tokens (several token groups per document, a running max per query token kept
+// across them: 32 more live registers, so it is a separate instantiation).
+template <bool COS, int NQ, bool MULTI>
+__global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
+    const float* __restrict__ tok, const uint32_t* __restrict__ doc_len, uint32_t ndocs, uint32_t T, uint32_t Tp,
+    uint32_t dim, const float* __restrict__ qtok /*[NQ][dim], zero-padded*/, uint32_t nq,
+    const float* __restrict__ q_aa /*[nq] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
+    bool first_pass) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];  // [NQ][qstride]
+    const int lane = threadIdx.x & 63;
+    const uint32_t docs_per_wave = 64 / Tp;
+    const uint32_t wave = (blockIdx.x * kMsThreads + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
+    const uint32_t chunks = dim / 4;
+    const uint32_t qstride = maxsim_qstride(dim);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * chunks * 4; i += kMsThreads) {
+        const uint32_t r = i / (chunks * 4), c = i - r * (chunks * 4);
+        s_q[r * qstride + c] = qtok[(size_t)r * dim + c];
+    }
+    __syncthreads();
+    for (uint32_t dbase = wave * docs_per_wave; dbase < ndocs; dbase += nwaves * docs_per_wave) {
+        const uint32_t doc = dbase + lane / Tp;
+        const uint32_t t = lane % Tp;
+        const uint32_t len = (doc < ndocs) ? (doc_len ? min(doc_len[doc], T) : T) : 0;
+        // documents with T > 64 tokens: walk the tokens in groups of Tp = 64, keeping a running max per query token
+        float best[NQ];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) best[qi] = -INFINITY;
+        for (uint32_t t0 = 0; t0 < (MULTI ? T : 1u); t0 += Tp) {
+            const bool live = (t0 + t) < len;
+            // lanes without a token read token 0 of the corpus (always mapped) and are masked out of the max below:
+            // no per-load predication in the hot loop
+            const float* row = tok + (live ? ((size_t)doc * T + t0 + t) * dim : (size_t)0);
+            f32x2 acc[NQ][2];
+            float bb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = f32x2{0.0f, 0.0f};
+            // bursts of 8 chunks (32 dims = one 128-B line of this lane's token row); per accumulator the chunks
+            // are visited in ascending order, which is all dot_portable's result depends on
+            uint32_t c0 = 0;
+#pragma unroll 1
+            for (; c0 + kMsBurst <= chunks; c0 += kMsBurst) maxsim_burst<NQ, true>(acc, bb, row, s_q, qstride, c0, chunks, lane, COS);
+            if (c0 < chunks) maxsim_burst<NQ, false>(acc, bb, row, s_q, qstride, c0, chunks, lane, COS);
+            // ((s0+s1)+s2)+s3 then the sequential tail (dense.rs:119-124)
+            float sbb = ex::add(ex::add(ex::add(bb[0], bb[1]), bb[2]), bb[3]);
+            float tailv[3] = {0.f, 0.f, 0.f};
+            const uint32_t ntail = dim - chunks * 4;
+            for (uint32_t e = 0; e < ntail; ++e) {
+                tailv[e] = row[chunks * 4 + e];
+                if (COS) sbb = ex::mad2(sbb, tailv[e], tailv[e]);
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                if ((uint32_t)qi < nq) {
+                    float sdot = ex::add(ex::add(ex::add(acc[qi][0].x, acc[qi][0].y), acc[qi][1].x), acc[qi][1].y);
+                    for (uint32_t e = 0; e < ntail; ++e) sdot = ex::mad2(sdot, qtok[(size_t)qi * dim + chunks * 4 + e], tailv[e]);
+                    float sc = sdot;
+                    if (COS) {  // dense.rs:341-345
+                        const float aa = q_aa[qi];
+                        constexpr float kEpsSq = INNR_NORM_EPSILON * INNR_NORM_EPSILON;  // lib.rs:184
+                        sc = (aa > kEpsSq && sbb > kEpsSq) ? ex::div(sdot, ex::mul(ex::sqrt(aa), ex::sqrt(sbb))) : 0.0f;
+                    }
+                    sc = live ? sc : -INFINITY;  // tokens beyond the document's length do not take part in the max
+                    best[qi] = fmaxf(best[qi], wave_max_seg(sc, (int)Tp));
+                }
+            }
+        }
+        // sum over query tokens in token order, folded from -0.0 (first pass) or from the previous passes' total
+        if (t == 0 && doc < ndocs) {
+            float total = first_pass ? -0.0f : partial_in[doc];
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi)
+                if ((uint32_t)qi < nq) total = ex::add(total, best[qi]);
+            out[doc] = (len == 0) ? 0.0f : total;  // empty document -> 0.0 (maxsim.rs:97-99)
+        }
+    }
+}
+
+// aa[i] = sum of squares of query token i in cosine_portable's 4-way order (dense.rs:288-339)
+__global__ void query_token_sq_kernel(const float* __restrict__ qtok, uint32_t nq, uint32_t dim, float* __restrict__ aa) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float* a = qtok + (size_t)i * dim;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t chunks = dim / 4;
+    for (uint32_t c = 0; c < chunks; ++c)
+        for (int e = 0; e < 4; ++e) s[e] = ex::mad2(s[e], a[4 * c + e], a[4 * c + e]);
+    float r = ex::add(ex::add(ex::add(s[0], s[1]), s[2]), s[3]);
+    for (uint32_t d = chunks * 4; d < dim; ++d) r = ex::mad2(r, a[d], a[d]);
+    aa[i] = r;
+}
+
+// synthetic documents: token (doc, t) = generate_normalized-style row of the uniform stream:
+// x = uniform row (row0 + doc*T + t); norm = sqrt(sum x*x) sequential from -0.0; x /= norm if norm > f32::EPSILON
+// (examples/maxsim_colbert.rs:212-228 with the uniform generator). One thread per token.
+__global__ void generate_tokens_kernel(float* __restrict__ tok, size_t ntok, uint32_t dim, uint64_t seed, uint64_t row0) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ntok) return;
+    float* row = tok + r * dim;
+    float ss = -0.0f;
+    for (uint32_t d = 0; d < dim; ++d) {
+        const float x = uniform_embedding(seed, row0 + r, dim, d);
+        ss = ex::mad2(ss, x, x);
+    }
+    const float norm = ex::sqrt(ss);
+    for (uint32_t d = 0; d < dim; ++d) {
+        const float x = uniform_embedding(seed, row0 + r, dim, d);
+        row[d] = (norm > 1.1920929e-07f) ? ex::div(x, norm) : x;
+    }
+}
+
+// Top-k of a dense score array (one "query"): threshold filter + per-wave lists, see topk_dev.h.
+template <int R>
+__global__ __launch_bounds__(256) void dense_filter_kernel(const float* __restrict__ scores, uint32_t N,
+                                                           uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
+                                                           uint32_t KP, uint32_t chunks_per_slot,
+                                                           uint32_t* __restrict__ errflag) {
+    constexpr uint32_t cap = 64 * R;
+    __shared__ uint32_t s_cnt[4], s_thr[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t slot = (size_t)blockIdx.x * 4 + w;
+    if (lane == 0) {
+        s_cnt[w] = 0;
+        s_thr[w] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const size_t nchunks = ((size_t)N + 255) / 256;
+    size_t ch0 = slot * chunks_per_slot, ch1 = ch0 + chunks_per_slot;
+    if (ch1 > nchunks) ch1 = nchunks;
+    uint64_t* my = lists + slot * cap;
+    for (size_t ch = ch0; ch < ch1; ++ch) {
+        const uint32_t thr = __hip_atomic_load(&s_thr[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t i = ch * 256 + (size_t)c * 64 + lane;
+            if (i < N) {
+                const uint32_t pref = f32_ord(scores[i]);
+                if (pref >= thr) cand_append(my, &s_cnt[w], cap, cand_make(pref, (uint32_t)i), errflag);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c = __builtin_amdgcn_readfirstlane(
+            __hip_atomic_load(&s_cnt[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+        if (c > cap - kBurst) {
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my, c, KP, &t);
+            if (lane == 0) {
+                s_cnt[w] = keep;
+                s_thr[w] = t;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t c = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_cnt[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+    if (c > KP) {
+        uint32_t t;
+        c = wave_compact<R>(my, c, KP, &t);
+    }
+    if (lane == 0) counts[slot] = c;
+}
+
+}  // namespace innr

@@ -44,3 +44,88 @@ def maxsim(query_tokens, doc_tokens) -> float:
 def maxsim_cosine(query_tokens, doc_tokens) -> float:
     """maxsim.rs:168-194"""
     return _maxsim(query_tokens, doc_tokens, 1)
+
+
+# ---- many documents: the device path -------------------------------------------------------------------------
+from typing import Optional, Sequence  # noqa: E402
+
+from . import _lib  # noqa: E402
+from ._lib import KnnStats, default_context  # noqa: E402
+
+
+class DocumentCorpus:
+    """Token embeddings of many documents resident on the GPU (addition: the reference scores one (query, doc)
+    pair per call and the caller loops and sorts, examples/maxsim_colbert.rs:171-187). `scores` returns
+    maxsim(query, doc_i) for every document, bit-identical to calling the reference in a loop; `topk` the k best
+    (score descending, ties -> lower document index)."""
+
+    def __init__(self, handle, ndocs: int, T: int, dim: int, ctx: _lib.Context):
+        self._h, self._n, self._T, self._dim, self._ctx = handle, int(ndocs), int(T), int(dim), ctx
+        ctx._children.add(self)
+
+    @classmethod
+    def from_tokens(cls, tokens, doc_len: Optional[Sequence[int]] = None, ctx: Optional[_lib.Context] = None):
+        """tokens: array [docs, T, dim]; doc_len[i] <= T = number of valid tokens of document i (default: T)."""
+        ctx = ctx or default_context()
+        t = np.ascontiguousarray(tokens, dtype=np.float32)
+        if t.ndim != 3:
+            raise InnrPanic("tokens must be [docs, T, dim]")
+        n, T, dim = t.shape
+        dl = None if doc_len is None else np.ascontiguousarray(doc_len, dtype=np.uint32)
+        if dl is not None and dl.size != n:
+            raise InnrPanic("doc_len.len() != docs")
+        h = C.c_void_p()
+        check(load().innr_maxsim_upload(ctx.handle, C.c_void_p(t.ctypes.data) if t.size else None,
+                                        C.c_void_p(dl.ctypes.data) if dl is not None and dl.size else None, n, T, dim,
+                                        C.byref(h)))
+        return cls(h, n, T, dim, ctx)
+
+    @classmethod
+    def generate(cls, ndocs: int, T: int, dim: int, seed: int = 0, row0: int = 0, ctx: Optional[_lib.Context] = None):
+        """Synthetic corpus made on the device: token (doc, t) = normalised uniform row (row0 + doc*T + t)."""
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        check(load().innr_maxsim_generate(ctx.handle, ndocs, T, dim, C.c_uint64(seed), C.c_uint64(row0), C.byref(h)))
+        return cls(h, ndocs, T, dim, ctx)
+
+    def __len__(self) -> int:
+        return self._n
+
+    def _q(self, query_tokens) -> np.ndarray:
+        q = _tokens(query_tokens, "query")
+        if q.shape[0] and self._T and self._n and q.shape[1] != self._dim:
+            raise InnrPanic("dimension mismatch (doc)")
+        return q
+
+    def scores(self, query_tokens, cosine: bool = False) -> np.ndarray:
+        q = self._q(query_tokens)
+        out = np.empty(self._n, dtype=np.float32)
+        check(load().innr_maxsim_scores(self._h, 1 if cosine else 0, C.c_void_p(q.ctypes.data) if q.size else None,
+                                        q.shape[0], self._dim if q.size == 0 else q.shape[1],
+                                        C.c_void_p(out.ctypes.data) if out.size else None))
+        return out
+
+    def topk(self, query_tokens, k: int, cosine: bool = False, stats: Optional[KnnStats] = None):
+        q = self._q(query_tokens)
+        kk = max(min(int(k), self._n), 1)
+        idx = np.empty(kk, dtype=np.uint64)
+        sc = np.empty(kk, dtype=np.float32)
+        out_k = C.c_size_t(0)
+        st = stats if stats is not None else KnnStats()
+        check(load().innr_maxsim_topk(self._h, 1 if cosine else 0, C.c_void_p(q.ctypes.data) if q.size else None,
+                                      q.shape[0], self._dim if q.size == 0 else q.shape[1], int(k),
+                                      C.c_void_p(idx.ctypes.data), C.c_void_p(sc.ctypes.data), C.byref(out_k), C.byref(st)))
+        r = int(out_k.value)
+        return idx[:r].copy(), sc[:r].copy()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            if getattr(self._ctx, "handle", None):
+                load().innr_docs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

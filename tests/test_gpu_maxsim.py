@@ -1,0 +1,108 @@
+"""GPU parity tests, part 5: maxsim / maxsim_cosine (src/maxsim.rs) over a device-resident document corpus --
+every document's score bit-identical to the oracle's portable path, top-k identical to a stable sort."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from test_gpu_exact import bits_equal
+
+
+@pytest.fixture(scope="module")
+def M():
+    from innr_amd import maxsim
+    return maxsim
+
+
+def _tokens(ndocs, T, dim, seed):
+    rows = oracle.generate_uniform(ndocs * T, dim, seed)
+    n = np.sqrt((rows.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    return (rows / np.maximum(n, 1e-12)).astype(np.float32).reshape(ndocs, T, dim)
+
+
+def _oracle_scores(q, toks, doc_len=None, cosine=False):
+    out = np.empty(len(toks), np.float32)
+    for i, d in enumerate(toks):
+        dd = d if doc_len is None else d[:doc_len[i]]
+        out[i] = oracle.maxsim(q, dd, cosine=cosine) if len(dd) else 0.0
+    return out
+
+
+@pytest.mark.parametrize("ndocs,T,dim,Tq", [(1, 1, 4, 1), (7, 3, 8, 2), (50, 64, 128, 32), (33, 16, 128, 32), (20, 64, 33, 5),
+                                            (9, 100, 64, 40), (300, 32, 96, 32)])
+def test_maxsim_scores_bit_exact(M, ndocs, T, dim, Tq):
+    toks = _tokens(ndocs, T, dim, 3)
+    q = _tokens(1, Tq, dim, 99)[0]
+    dc = M.DocumentCorpus.from_tokens(toks)
+    assert bits_equal(dc.scores(q), _oracle_scores(q, toks))
+    assert bits_equal(dc.scores(q, cosine=True), _oracle_scores(q, toks, cosine=True))
+    # unnormalised tokens and queries exercise the cosine guards/normalisation for real
+    toks2 = (toks * np.float32(3.5)).astype(np.float32)
+    toks2[0, 0, :] = 0.0  # zero-norm token -> cosine 0 (dense.rs:341-345)
+    dc2 = M.DocumentCorpus.from_tokens(toks2)
+    q2 = (q * np.float32(0.25)).astype(np.float32)
+    assert bits_equal(dc2.scores(q2, cosine=True), _oracle_scores(q2, toks2, cosine=True))
+    assert bits_equal(dc2.scores(q2), _oracle_scores(q2, toks2))
+
+
+def test_maxsim_doc_len_and_empties(M):
+    toks = _tokens(40, 20, 32, 5)
+    lens = np.array([(i * 7) % 21 for i in range(40)], dtype=np.uint32)  # includes 0 and 20
+    q = _tokens(1, 6, 32, 8)[0]
+    dc = M.DocumentCorpus.from_tokens(toks, lens)
+    assert bits_equal(dc.scores(q), _oracle_scores(q, toks, lens))
+    assert bits_equal(dc.scores(q, cosine=True), _oracle_scores(q, toks, lens, cosine=True))
+    assert np.all(dc.scores(np.empty((0, 32), np.float32)) == 0.0)  # empty query -> 0.0 (maxsim.rs:97)
+    i, s = dc.topk(q, 0)
+    assert len(i) == 0
+    from innr_amd import InnrPanic
+    with pytest.raises(InnrPanic):
+        dc.scores(np.ones((2, 31), np.float32))
+
+
+@pytest.mark.parametrize("ndocs,k", [(10, 3), (2000, 10), (5000, 100), (700, 240)])
+def test_maxsim_topk_equals_stable_sort(M, ndocs, k):
+    T, dim, Tq = 16, 64, 8
+    toks = _tokens(ndocs, T, dim, 12)
+    toks[5] = toks[3]  # exact tie between documents 3 and 5: lower index first
+    q = _tokens(1, Tq, dim, 4)[0]
+    dc = M.DocumentCorpus.from_tokens(toks)
+    for cosine in (False, True):
+        sc = _oracle_scores(q, toks, cosine=cosine)
+        order = np.argsort(-sc.astype(np.float64), kind="stable")[:k]
+        idx, s = dc.topk(q, k, cosine=cosine)
+        assert idx.tolist() == order.tolist() and bits_equal(s, sc[order])
+
+
+def test_maxsim_generated_corpus_matches_oracle_generator(M):
+    ndocs, T, dim = 64, 8, 32
+    dc = M.DocumentCorpus.generate(ndocs, T, dim, seed=5, row0=1000)
+    rows = oracle.generate_uniform(ndocs * T, dim, 5, row0=1000)
+    toks = np.empty_like(rows)
+    for r in range(len(rows)):  # generate_normalized order: sequential sum of squares from -0.0, divide by sqrt
+        ss = np.float32(-0.0)
+        for x in rows[r]:
+            ss = np.float32(ss + np.float32(x * x))
+        nrm = np.float32(np.sqrt(ss))
+        toks[r] = rows[r] / nrm if nrm > np.finfo(np.float32).eps else rows[r]
+    toks = toks.reshape(ndocs, T, dim)
+    q = _tokens(1, 4, dim, 1)[0]
+    assert bits_equal(dc.scores(q), _oracle_scores(q, toks))
+
+
+def test_maxsim_c4_shape_properties(M):
+    # BASELINE.json configs[3] at 1/10 scale for the oracle cross-check (100K docs x 64 x 128, 32-token query, top-100)
+    import innr_amd
+    ndocs, T, dim, Tq, k = 100_000, 64, 128, 32, 100
+    dc = M.DocumentCorpus.generate(ndocs, T, dim, seed=0)
+    q = _tokens(1, Tq, dim, 123)[0]
+    st = innr_amd.KnnStats()
+    idx, sc = dc.topk(q, k, stats=st)
+    allsc = dc.scores(q)
+    order = np.argsort(-allsc.astype(np.float64), kind="stable")[:k]
+    assert idx.tolist() == order.tolist() and bits_equal(sc, allsc[order])
+    print(f"maxsim 100Kx64x128 Tq=32: scan {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms -> "
+          f"{ndocs*T*dim*4/st.gemm_ms/1e6:.0f} GB/s")

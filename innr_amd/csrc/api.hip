@@ -1283,28 +1283,25 @@ static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok
     const uint32_t docs_per_wave = 64 / Tp;
     const size_t nwaves_needed = (d->ndocs + docs_per_wave - 1) / docs_per_wave;
     const unsigned blocks = (unsigned)std::min<size_t>((nwaves_needed + 3) / 4, (size_t)c->num_cus * 2);
-    // query tokens per pass: as many as fit 64 KB of LDS (32 up to dim 508, 16 up to 1020, 8 up to 2044)
-    const uint32_t qstride = maxsim_qstride((uint32_t)dim);
-    size_t per_pass = kMsQ;
-    while (per_pass > 8 && per_pass * qstride * sizeof(float) > 64 * 1024) per_pass /= 2;
-    if (per_pass * qstride * sizeof(float) > 64 * 1024) {
-        set_error("maxsim: token dimension %zu not supported (max 2044)", dim);
-        return INNR_E_UNSUPPORTED;
-    }
-    for (size_t p0 = 0; p0 < Tq; p0 += per_pass) {
-        const uint32_t nq = (uint32_t)std::min<size_t>(per_pass, Tq - p0);
+    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * dim * sizeof(float)));  // packed copy of one pass of query tokens
+    float* qpk = c->q_kmajor.as<float>();
+    for (size_t p0 = 0; p0 < Tq; p0 += kMsQ) {
+        const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
         const float* qp = c->q_row.as<float>() + p0 * dim;
         const float* aa = c->q_norm.as<float>() + p0;
 #define INNR_MS_LAUNCH(COSV, NQV)                                                                                       \
     do {                                                                                                                \
+        const unsigned npk = (unsigned)(dim / 4) * NQV * 4;                                                             \
+        if (npk)                                                                                                        \
+            maxsim_pack_query_kernel<<<(npk + 255) / 256, 256, 0, c->stream>>>(qp, NQV, (uint32_t)dim, qpk);            \
         if (d->T > 64)                                                                                                  \
-            maxsim_scan_kernel<COSV, NQV, true><<<blocks, kMsThreads, (size_t)NQV * qstride * sizeof(float), c->stream>>>( \
-                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, nq, COSV ? aa : nullptr,  \
-                out, out, p0 == 0);                                                                                     \
+            maxsim_scan_kernel<COSV, NQV, true><<<blocks, kMsThreads, 0, c->stream>>>(                                  \
+                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                 \
+                COSV ? aa : nullptr, out, out, p0 == 0);                                                                \
         else                                                                                                            \
-            maxsim_scan_kernel<COSV, NQV, false><<<blocks, kMsThreads, (size_t)NQV * qstride * sizeof(float), c->stream>>>( \
-                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, nq, COSV ? aa : nullptr,  \
-                out, out, p0 == 0);                                                                                     \
+            maxsim_scan_kernel<COSV, NQV, false><<<blocks, kMsThreads, 0, c->stream>>>(                                 \
+                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                 \
+                COSV ? aa : nullptr, out, out, p0 == 0);                                                                \
     } while (0)
         if (cosine) {
             if (nq <= 8) INNR_MS_LAUNCH(true, 8); else if (nq <= 16) INNR_MS_LAUNCH(true, 16); else INNR_MS_LAUNCH(true, 32);

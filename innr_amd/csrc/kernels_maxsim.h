@@ -17,6 +17,8 @@
 // token row in 128-B bursts (8 x dwordx4 in flight: a burst is one cache line, fetched once).
 #pragma once
 
+#include <utility>
+
 #include "common.h"
 
 namespace innr {
@@ -38,111 +40,124 @@ __device__ __forceinline__ float wave_max_seg(float v, int seg) {  // fmaxf over
 // NQ (8/16/32) = query tokens per pass, a compile-time bound so the hot loop has no per-token branch. The query
 // buffer is zero-padded to NQ tokens; padded tokens are computed and ignored (only qi < nq enter the sum).
 //
-// Query operands. Every lane needs every query value q[qi][d] as a wave-uniform multiplier. Three ways were
-// measured on 100K docs x 64 x 128, Tq = 32:
+// Query operands. Every lane needs every query value q[qi][d] as a wave-uniform multiplier. Measured on 100K docs x
+// 64 x 128, Tq = 32 (tools/maxsim_probe.hip, tools/valu_rate.hip):
 //   * LDS broadcast reads (ds_read_b128 per (qi, chunk)): 32 reads per chunk per wave keep the CU's one LDS pipe
 //     as busy as the VALU -- 4.3 ms;
-//   * scalar loads (wave-uniform global reads -> s_load_dwordx4): hipcc serialises {s_load, wait, 8 VALU} and
-//     at 100+ SGPRs cannot keep loads in flight -- 3.2 ms;
-//   * THIS: the query sits in LDS (rows padded to an odd number of 16-B units: conflict-free), each lane reads
-//     ONE float4 per two chunks -- lane l holds q[l & 31][chunk c + (l >> 5)] -- and v_readlane_b32 broadcasts a
-//     value into an SGPR right before its mul. 1.5 VALU-issue slots per MAC-half instead of 1, but no memory
-//     pipe on the critical path at all.
-// q[0..3] = lane `src` of v.x, v.y, v.z, v.w as wave-uniform values (SGPRs). Inline asm because the builtin
-// (__builtin_amdgcn_readlane) is hoisted freely by the compiler, see maxsim_burst.
-__device__ __forceinline__ void bcast4(float (&q)[4], const float4& v, int src) {
-    asm volatile(
-        "v_readlane_b32 %0, %4, %8\n\tv_readlane_b32 %1, %5, %8\n\tv_readlane_b32 %2, %6, %8\n\tv_readlane_b32 %3, %7, %8"
-        : "=s"(q[0]), "=s"(q[1]), "=s"(q[2]), "=s"(q[3])
-        : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "n"(src));
+//   * compiler-scheduled scalar loads (wave-uniform global reads -> s_load_dwordx4): hipcc serialises
+//     {s_load, wait, 8 VALU} and cannot keep loads in flight -- 3.2 ms;
+//   * query in LDS, one float4 per lane per two chunks, v_readlane_b32 into an SGPR before each mul: v_readlane
+//     issues at ~5-6 cycles, 4 of them per 4 packed mul/add -- 2.3 ms, VALU-issue bound;
+//   * THIS: the query is re-packed in global memory as qpk[chunk][qi][4] so that ONE s_load_dwordx16 brings the
+//     operands of 4 query tokens x 4 dims (= 16 packed VALU ops); loads are issued by hand one group ahead of
+//     their use, double-buffered in 2 x 16 SGPRs. The scalar cache holds the whole packed query (16 KB).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Asynchronous: dst is valid only after swait0(dst). The compiler sees dst as defined here and keeps its
+// registers untouched until swait0's tied operand "uses" them (checked in the ISA: no copy in between).
+template <int BYTE_OFF>
+__device__ __forceinline__ void sload16(f32x16& dst, const float* p) {
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(dst) : "s"(p), "n"(BYTE_OFF));
+}
+__device__ __forceinline__ void swait0(f32x16& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
+
+// 4 query tokens (qi0..qi0+3) x one 4-dim chunk: fl(acc + fl(q*d)) per element, as packed pairs
+// (v_pk_mul_f32 + v_pk_add_f32; the library is built -ffp-contract=off).
+template <int NQ>
+__device__ __forceinline__ void maxsim_group(f32x2 (&acc)[NQ][2], const f32x16& q, int qi0, const float4& d) {
+    const f32x2 d01 = {d.x, d.y}, d23 = {d.z, d.w};
+    // two tokens at a time: four products, then four sums -- a dependent packed op issued within 3 slots of its
+    // producer costs s_nops on gfx950
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        const f32x2 qa01 = {q[4 * j + 0], q[4 * j + 1]}, qa23 = {q[4 * j + 2], q[4 * j + 3]};
+        const f32x2 qb01 = {q[4 * j + 4], q[4 * j + 5]}, qb23 = {q[4 * j + 6], q[4 * j + 7]};
+        f32x2 ta01 = qa01 * d01, ta23 = qa23 * d23, tb01 = qb01 * d01, tb23 = qb23 * d23;
+        asm volatile("" : "+v"(ta01), "+v"(ta23), "+v"(tb01), "+v"(tb23));
+        acc[qi0 + j][0] = acc[qi0 + j][0] + ta01;
+        acc[qi0 + j][1] = acc[qi0 + j][1] + ta23;
+        acc[qi0 + j + 1][0] = acc[qi0 + j + 1][0] + tb01;
+        acc[qi0 + j + 1][1] = acc[qi0 + j + 1][1] + tb23;
+        // pin the results here: pure arithmetic would otherwise drift away from the loads that feed it
+        asm volatile("" : "+v"(acc[qi0 + j][0]), "+v"(acc[qi0 + j][1]), "+v"(acc[qi0 + j + 1][0]), "+v"(acc[qi0 + j + 1][1]));
+    }
 }
 
-template <int NQ, bool FULL>
-__device__ __forceinline__ void maxsim_burst(f32x2 (&acc)[NQ][2], float (&bb)[4], const float* __restrict__ row,
-                                             const float* s_q, uint32_t qstride, uint32_t c0, uint32_t chunks,
-                                             int lane, bool cos) {
-    float4 dv[kMsBurst];
-#pragma unroll
-    for (int b = 0; b < kMsBurst; ++b)
-        if (FULL || c0 + b < chunks) {
-#ifdef INNR_MS_PROBE_NOLOAD  // tools/maxsim_probe.hip: arithmetic only
-            dv[b] = make_float4((float)(c0 + b), (float)lane, 1.0f, 2.0f);
+__device__ __forceinline__ void maxsim_bb(float (&bb)[4], const float4& d) {
+    bb[0] = ex::mad2(bb[0], d.x, d.x);
+    bb[1] = ex::mad2(bb[1], d.y, d.y);
+    bb[2] = ex::mad2(bb[2], d.z, d.z);
+    bb[3] = ex::mad2(bb[3], d.w, d.w);
+}
+
+// One full burst: 8 chunks x NQ/4 groups, software-pipelined over the flat group sequence g = 0..G-1 (a pack
+// expansion, so that every load offset is an immediate). qb = packed query at chunk c0: group (b, gi) sits at
+// qb + (b*NQ + 4*gi)*4 floats.
+template <int NQ, bool COS, int g>
+__device__ __forceinline__ void maxsim_step(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                            const float* qb, f32x16 (&buf)[2]) {
+    constexpr int GPC = NQ / 4, G = kMsBurst * GPC, b = g / GPC, gi = g % GPC;
+#ifdef INNR_MS_PROBE_NOMATH  // tools/maxsim_probe.hip: loads only (one group's arithmetic per chunk keeps them live)
+    if (gi > 0) return;
+    swait0(buf[b & 1]);
+    if (g + GPC < G) sload16<((g + GPC) / GPC) * NQ * 16>(buf[(b + 1) & 1], qb);
+    maxsim_group<NQ>(acc, buf[b & 1], 0, dv[b]);
 #else
-            dv[b] = *reinterpret_cast<const float4*>(row + 4 * (c0 + b));
+    swait0(buf[g & 1]);
+    if (g + 1 < G) sload16<(((g + 1) / GPC) * NQ + 4 * ((g + 1) % GPC)) * 16>(buf[(g + 1) & 1], qb);
+    if (COS && gi == 0) maxsim_bb(bb, dv[b]);
+    maxsim_group<NQ>(acc, buf[g & 1], 4 * gi, dv[b]);
 #endif
-        }
-    float4 vq[kMsBurst / 2];
-    const uint32_t qrow = ((uint32_t)lane & 31u) % (uint32_t)NQ;
-#pragma unroll
-    for (int p = 0; p < kMsBurst / 2; ++p) {
-        const uint32_t c = c0 + 2 * p + ((uint32_t)lane >> 5);
-        vq[p] = (FULL || c < chunks) ? *reinterpret_cast<const float4*>(s_q + qrow * qstride + 4 * c)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+}
+
+template <int NQ, bool COS, int... g>
+__device__ __forceinline__ void maxsim_burst_seq(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                                 const float* qb, std::integer_sequence<int, g...>) {
+    f32x16 buf[2];
+    sload16<0>(buf[0], qb);
+    (maxsim_step<NQ, COS, g>(acc, bb, dv, qb, buf), ...);
+}
+
+template <int NQ, bool COS>
+__device__ __forceinline__ void maxsim_burst(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                             const float* qb) {
+    maxsim_burst_seq<NQ, COS>(acc, bb, dv, qb, std::make_integer_sequence<int, kMsBurst * (NQ / 4)>{});
+}
+
+__device__ __forceinline__ void maxsim_load_burst(float4 (&dv)[kMsBurst], const float* __restrict__ row, uint32_t c0, int lane) {
 #pragma unroll
     for (int b = 0; b < kMsBurst; ++b) {
-        if (FULL || c0 + b < chunks) {  // wave-uniform
-            if (cos) {
-                bb[0] = ex::mad2(bb[0], dv[b].x, dv[b].x);
-                bb[1] = ex::mad2(bb[1], dv[b].y, dv[b].y);
-                bb[2] = ex::mad2(bb[2], dv[b].z, dv[b].z);
-                bb[3] = ex::mad2(bb[3], dv[b].w, dv[b].w);
-            }
-            const float4 v = vq[b >> 1];
-            // software pipeline, pinned with sched_barrier: the 4 v_readlane of token qi+1 issue next to the 4
-            // mul/add of token qi (gfx950 wants 2 wait states between a VALU SGPR write and its VALU read). Left
-            // to itself the scheduler hoists all 128 readlanes of a chunk, runs out of SGPRs and spills them.
-            float qn[4], qc[4];
-            const int src0 = (b & 1) * 32;
-            bcast4(qc, v, src0);
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) {
-#ifdef INNR_MS_PROBE_NOMATH  // tools/maxsim_probe.hip: loads only (one token's arithmetic keeps them live)
-                if (qi > 0) break;
+#ifdef INNR_MS_PROBE_NOLOAD  // tools/maxsim_probe.hip: arithmetic only
+        dv[b] = make_float4((float)(c0 + b), (float)lane, 1.0f, 2.0f);
+#else
+        dv[b] = *reinterpret_cast<const float4*>(row + 4 * (c0 + b));
 #endif
-                __builtin_amdgcn_sched_barrier(0);
-                if (qi + 1 < NQ) bcast4(qn, v, src0 + qi + 1);
-                // two packed pairs: fl(acc + fl(q*d)) per element (v_pk_mul_f32 + v_pk_add_f32; -ffp-contract=off)
-                const f32x2 q01 = {qc[0], qc[1]}, q23 = {qc[2], qc[3]};
-                const f32x2 d01 = {dv[b].x, dv[b].y}, d23 = {dv[b].z, dv[b].w};
-                f32x2 t01 = q01 * d01, t23 = q23 * d23;
-                asm volatile("" : "+v"(t01), "+v"(t23));  // both products before either sum: no back-to-back dependency
-                acc[qi][0] = acc[qi][0] + t01;
-                acc[qi][1] = acc[qi][1] + t23;
-                // pin the results here (pure arithmetic would otherwise sink below all the broadcasts)
-                asm volatile("" : "+v"(acc[qi][0]), "+v"(acc[qi][1]));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qc[e] = qn[e];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
 }
 
-// LDS row stride (floats) of the staged query: >= 4*chunks, an ODD number of 16-B units so that the 32 rows a
-// ds_read_b128 touches fall in distinct bank groups.
-__host__ __device__ inline uint32_t maxsim_qstride(uint32_t dim) { return 4u * ((dim / 4u) | 1u); }
+// qpk[(c*NQ + qi)*4 + e] = qtok[qi*dim + 4c + e] (qi >= nq_valid rows are zero in qtok already)
+__global__ void maxsim_pack_query_kernel(const float* __restrict__ qtok, uint32_t NQ, uint32_t dim, float* __restrict__ qpk) {
+    const uint32_t chunks = dim / 4;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunks * NQ * 4) return;
+    const uint32_t e = i & 3, qi = (i >> 2) % NQ, c = (i >> 2) / NQ;
+    qpk[i] = qtok[(size_t)qi * dim + 4 * c + e];
+}
 
 // MULTI: documents longer than 64 tokens (several token groups per document, a running max per query token kept
 // across them: 32 more live registers, so it is a separate instantiation).
 template <bool COS, int NQ, bool MULTI>
 __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
     const float* __restrict__ tok, const uint32_t* __restrict__ doc_len, uint32_t ndocs, uint32_t T, uint32_t Tp,
-    uint32_t dim, const float* __restrict__ qtok /*[NQ][dim], zero-padded*/, uint32_t nq,
+    uint32_t dim, const float* __restrict__ qtok /*[NQ][dim], zero-padded*/,
+    const float* __restrict__ qpk /*[dim/4][NQ][4] packed copy*/, uint32_t nq,
     const float* __restrict__ q_aa /*[nq] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
     bool first_pass) {
-    extern __shared__ __attribute__((aligned(16))) float s_q[];  // [NQ][qstride]
     const int lane = threadIdx.x & 63;
     const uint32_t docs_per_wave = 64 / Tp;
     const uint32_t wave = (blockIdx.x * kMsThreads + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
     const uint32_t chunks = dim / 4;
-    const uint32_t qstride = maxsim_qstride(dim);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * chunks * 4; i += kMsThreads) {
-        const uint32_t r = i / (chunks * 4), c = i - r * (chunks * 4);
-        s_q[r * qstride + c] = qtok[(size_t)r * dim + c];
-    }
-    __syncthreads();
     for (uint32_t dbase = wave * docs_per_wave; dbase < ndocs; dbase += nwaves * docs_per_wave) {
         const uint32_t doc = dbase + lane / Tp;
         const uint32_t t = lane % Tp;
@@ -160,12 +175,34 @@ __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
             float bb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = f32x2{0.0f, 0.0f};
-            // bursts of 8 chunks (32 dims = one 128-B line of this lane's token row); per accumulator the chunks
-            // are visited in ascending order, which is all dot_portable's result depends on
+            // bursts of 8 chunks (32 dims = one 128-B line of this lane's token row), the next burst's line already
+            // in flight while this one is multiplied; per accumulator the chunks are visited in ascending order,
+            // which is all dot_portable's result depends on
             uint32_t c0 = 0;
+            float4 dv[kMsBurst], dn[kMsBurst];
+            if (kMsBurst <= chunks) maxsim_load_burst(dv, row, 0, lane);
 #pragma unroll 1
-            for (; c0 + kMsBurst <= chunks; c0 += kMsBurst) maxsim_burst<NQ, true>(acc, bb, row, s_q, qstride, c0, chunks, lane, COS);
-            if (c0 < chunks) maxsim_burst<NQ, false>(acc, bb, row, s_q, qstride, c0, chunks, lane, COS);
+            for (; c0 + kMsBurst <= chunks; c0 += kMsBurst) {
+                const bool more = c0 + 2 * kMsBurst <= chunks;  // wave-uniform
+                if (more) maxsim_load_burst(dn, row, c0 + kMsBurst, lane);
+                maxsim_burst<NQ, COS>(acc, bb, dv, qpk + (size_t)c0 * NQ * 4);
+                if (more) {
+#pragma unroll
+                    for (int b = 0; b < kMsBurst; ++b) dv[b] = dn[b];
+                }
+            }
+            // remaining chunks (dim not a multiple of 32): one group at a time, not pipelined
+            for (; c0 < chunks; ++c0) {
+                const float4 d4 = *reinterpret_cast<const float4*>(row + 4 * c0);
+                if (COS) maxsim_bb(bb, d4);
+#pragma unroll
+                for (int gi = 0; gi < NQ / 4; ++gi) {
+                    f32x16 q;
+                    sload16<0>(q, qpk + ((size_t)c0 * NQ + 4 * gi) * 4);
+                    swait0(q);
+                    maxsim_group<NQ>(acc, q, 4 * gi, d4);
+                }
+            }
             // ((s0+s1)+s2)+s3 then the sequential tail (dense.rs:119-124)
             float sbb = ex::add(ex::add(ex::add(bb[0], bb[1]), bb[2]), bb[3]);
             float tailv[3] = {0.f, 0.f, 0.f};

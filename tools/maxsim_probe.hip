@@ -20,7 +20,9 @@ int main(int argc, char** argv) {
     generate_tokens_kernel<<<(unsigned)((ndocs * T + 255) / 256), 256>>>(tok, ndocs * T, dim, 1, 0);
     generate_tokens_kernel<<<1, 64>>>(q, NQ, dim, 2, 0);
     CK(hipDeviceSynchronize());
-    const uint32_t qs = maxsim_qstride(dim);
+    float* qpk;
+    CK(hipMalloc(&qpk, NQ * dim * 4));
+    maxsim_pack_query_kernel<<<(NQ * dim + 255) / 256, 256>>>(q, NQ, dim, qpk);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     for (int blocks_per_cu = 1; blocks_per_cu <= 3; ++blocks_per_cu) {
@@ -28,7 +30,7 @@ int main(int argc, char** argv) {
         float best = 1e9;
         for (int it = 0; it < 5; ++it) {
             hipEventRecord(a);
-            maxsim_scan_kernel<false, 32, false><<<blocks, kMsThreads, NQ * qs * 4>>>(tok, nullptr, (uint32_t)ndocs, T, 64, dim, q, NQ, nullptr, out, out, true);
+            maxsim_scan_kernel<false, 32, false><<<blocks, kMsThreads>>>(tok, nullptr, (uint32_t)ndocs, T, 64, dim, q, qpk, NQ, nullptr, out, out, true);
             hipEventRecord(b);
             CK(hipEventSynchronize(b));
             float ms; hipEventElapsedTime(&ms, a, b);

@@ -39,13 +39,13 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
     rows = oracle.generate_uniform(n, dim, 0)
     data = oracle.from_rows(rows)
     del rows
-    queries = oracle.generate_uniform(64, dim, 0xBE7C)
+    queries = oracle.generate_uniform(128, dim, 0xBE7C)
     oracle.batch_knn_dot(queries[0], data[:, :1000].copy(), k)  # warm the library
     done, t0 = 0, time.perf_counter()
     while done < len(queries):
         oracle.batch_knn_dot(queries[done], data, k)
         done += 1
-        if time.perf_counter() - t0 >= budget_s or done >= 16:
+        if time.perf_counter() - t0 >= budget_s:
             break
     dt = time.perf_counter() - t0
     return {
@@ -57,6 +57,29 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
         "sample": f"oracle batch_knn_dot (scan + full stable sort), {done} queries x {n} x {dim} f32 uniform(-1,1), k={k}, "
                   f"{dt:.1f} s on 1 host thread; the scan is O(N) so vectors/s carries to 10M",
     }
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of THIS command (profiles/, collected
+    in separate --pmc runs: a counter pass cannot share a run with the timed region). FETCH_SIZE/WRITE_SIZE are in
+    KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads -> x2 (MI355X_MICROARCH.md,
+    section HBM; calibrated here on norms_kernel: 1.50e7 KB reported for a 30.72 GB read)."""
+    default = (args.n_per_gpu, args.dim, args.queries, args.k, args.metric) == (10_000_000, 768, 1024, 10, "dot")
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r01_bench_n1_pmc_{name}.csv")
+        if not default or not os.path.exists(path):
+            return {"traffic": None}
+        for line in open(path):
+            if "gemm_filter_kernel" in line and f",{name}," in line:
+                vals[name] = float(line.rsplit(",", 1)[1])
+    if len(vals) != 2:
+        return {"traffic": None}
+    rd, wr = vals["FETCH_SIZE"] * 1024.0 * 2.0, vals["WRITE_SIZE"] * 1024.0
+    return {"traffic": rd + wr, "traffic_unit": "bytes per launch",
+            "traffic_source": "profiles/r01_bench_n1_pmc_{FETCH,WRITE}_SIZE.csv (FETCH_SIZE x2 gfx950 correction; "
+                              "L2-miss side, Infinity-Cache hits included)",
+            "algorithmic_bytes_per_launch": 4.0 * args.n_per_gpu * args.dim}
 
 
 def main() -> None:
@@ -89,7 +112,6 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import oracle  # queries come from the shared uniform stream (generation only; nothing on the timed path)
     from innr_amd import KNN_MFMA, METRIC_COSINE, METRIC_DOT, Context, KnnStats
     from innr_amd import batch as B
     from innr_amd.dist import ShardedKnn
@@ -103,7 +125,10 @@ def main() -> None:
     vb = B.VerticalBatch.generate(args.n_per_gpu, args.dim, seed=0, row0=row0, ctx=ctx)  # resident in HBM
     if sk is not None:
         sk.attach_gpu_batch(vb, metric, KNN_MFMA)
-    q_host = oracle.generate_uniform(args.queries, args.dim, 0xBE7C)
+    # queries: rows of the same uniform stream under another seed, generated by the library on the device
+    qb = B.VerticalBatch.generate(args.queries, args.dim, seed=0xBE7C, ctx=ctx)
+    q_host = np.ascontiguousarray(np.asarray(qb.data(), dtype=np.float32).reshape(args.dim, args.queries).T)
+    qb.close()
     q_dev = torch.from_numpy(q_host).to(dev)  # resident in HBM before the timed region
 
     from innr_amd.dist import _gpu_local_search
@@ -176,7 +201,7 @@ def main() -> None:
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "kernel_ms": g_ms,
                 "algorithmic_flop_per_launch": flop,
-                "traffic": None,
+                **pmc_traffic(args),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -294,7 +294,7 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
 // ---- GEMM engine -------------------------------------------------------------------------------------
 struct GemmPlan {
     size_t Qpad;
-    uint32_t nqt, nslices, tps, KP, cap, nblocks;
+    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks;
 };
 
 static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
@@ -310,6 +310,19 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
     p.nslices = ns;
     p.tps = (ntiles + ns - 1) / ns;
     p.nblocks = p.nqt * ns;
+    // query tiles per XCD group (see gemm_filter_kernel): the smallest divisor of nqt that is >= the preferred group
+    // size and leaves a group count dividing the 8 XCDs (g = nqt always qualifies)
+    // Preferred 1: measured at C2 (rocprofv3 FETCH_SIZE x2): 123 GB of L2-miss reads per launch with 1 tile per XCD
+    // group, 130 GB with 2, 191 GB with 4 -- blocks that share a slice drift further apart than a 4 MB L2 can
+    // bridge, so co-locating query tiles buys no corpus reuse and only evicts queries. Same speed either way.
+    uint32_t want = 1;
+    if (const char* e = getenv("INNR_GEMM_QT_GROUP")) want = (uint32_t)std::max(1, atoi(e));
+    p.qtg = p.nqt;
+    for (uint32_t g = std::min(want, p.nqt); g <= p.nqt; ++g)
+        if (p.nqt % g == 0 && 8 % (p.nqt / g) == 0) {
+            p.qtg = g;
+            break;
+        }
     return p;
 }
 
@@ -328,7 +341,7 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
 #define INNR_GEMM_LAUNCH(RR)                                                                                    \
     gemm_filter_kernel<KIND, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
-        p.nqt, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
+        p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
         ld_dump)
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;

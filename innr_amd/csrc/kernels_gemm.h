@@ -99,7 +99,7 @@ enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2 };
 template <int KIND, int R, int MODE>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
-    uint32_t nqt, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
+    uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
     uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
     constexpr bool COS = KIND == kGemmCos;
@@ -109,10 +109,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     __shared__ GemmLds s;
     constexpr uint32_t cap = 64 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // blocks b, b+8, ... share an XCD (round-robin dispatch): give them the query tiles of ONE corpus slice
+    // Blocks b, b+8, ... share an XCD and its 4 MB L2 (round-robin dispatch). An XCD works on a group of `qtg`
+    // query tiles (qtg | nqt, (nqt/qtg) | 8): its consecutive blocks take the qtg tiles of ONE corpus slice, so a
+    // streamed corpus tile is fetched from HBM once per group while only qtg x 768 KB of queries must stay in L2.
+    // qtg = nqt: corpus read once, all queries resident per XCD; qtg = 1: corpus read nqt times, one query tile.
     const uint32_t b = blockIdx.x;
-    const uint32_t slice = (b / (8 * nqt)) * 8 + (b & 7);
-    const uint32_t qt = (b >> 3) % nqt;
+    const uint32_t xcd = b & 7, lb = b >> 3, groups = nqt / qtg;
+    const uint32_t qt = (xcd % groups) * qtg + lb % qtg;
+    const uint32_t slice = (lb / qtg) * (8 / groups) + xcd / groups;
     const size_t q0 = (size_t)qt * kBQ;
     const uint32_t ntiles = (uint32_t)(ldN / kBC);
     uint32_t t0 = slice * tiles_per_slice, t1 = t0 + tiles_per_slice;

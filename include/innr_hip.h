@@ -163,8 +163,11 @@ innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base);
  * to the portable path (dot_portable / cosine_portable order). qtok: [Tq*dim]. Empty query/document -> 0.0. */
 innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, float* out);
 /* the k best documents by that score, descending, ties -> lower document index (a stable sort of the scores, as
- * the reference example does). stats->gemm_ms = device time of the scan. */
-innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
+ * the reference example does); scores are the exact maxsim values under either engine.
+ * engine: INNR_KNN_EXACT = exact scan of every document; INNR_KNN_MFMA = approximate scores on the matrix cores,
+ * exact re-score of the best candidates and a margin proof (unproven -> redone exactly, stats->queries_fallback = 1;
+ * needs T > 16, dim % 8 == 0, dim <= 512); INNR_KNN_AUTO picks. stats->gemm_ms = device time of the corpus scan. */
+innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
                              uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats);
 
 /* ---- L2 variants of the batch module (exact engine, one query) -------------------------------------- */

@@ -1182,6 +1182,8 @@ struct innr_docs {
     size_t ndocs = 0, T = 0, dim = 0;
     float* tok = nullptr;          // [ndocs][T][dim]
     uint32_t* doc_len = nullptr;   // [ndocs] or null (every document has T tokens)
+    float* tok_inv = nullptr;      // [ndocs*T] 1/|token| (0 for zero-norm tokens), built on first MFMA-engine use
+    float max_norm = 0.0f;         // max |token| over the corpus
     uint64_t index_base = 0;
 };
 
@@ -1256,6 +1258,7 @@ void innr_docs_free(innr_docs* d) {
     }
     if (d->tok) (void)hipFree(d->tok);
     if (d->doc_len) (void)hipFree(d->doc_len);
+    if (d->tok_inv) (void)hipFree(d->tok_inv);
     delete d;
 }
 
@@ -1267,23 +1270,12 @@ innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base) {
     return INNR_OK;
 }
 
-// scores of every document into c->scores (device); q tokens uploaded from the host
-static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim) {
+// ---- query staging: tokens zero-padded to a multiple of kMsQ in c->q_row, exact squared norms in c->q_norm (cosine)
+static innr_status maxsim_stage_query(innr_docs* d, int cosine, const float* qtok, size_t Tq) {
     innr_ctx* c = d->ctx;
-    if (dim != d->dim) {  // maxsim.rs:103-110
-        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
-        return INNR_E_DIM_MISMATCH;
-    }
-    INNR_TRY(c->scores.ensure(std::max<size_t>(d->ndocs, 1) * sizeof(float)));
-    float* out = c->scores.as<float>();
-    if (Tq == 0 || d->T == 0 || d->ndocs == 0) {  // maxsim.rs:97-99: empty query or empty documents -> 0.0
-        INNR_HIP_CHECK(hipMemsetAsync(out, 0, std::max<size_t>(d->ndocs, 1) * sizeof(float), c->stream));
-        return INNR_OK;
-    }
-    // query tokens zero-padded to a multiple of kMsQ so every pass can read a full block of tokens
-    const size_t Tq_pad = round_up(Tq, kMsQ);
+    const size_t dim = d->dim, Tq_pad = round_up(Tq, kMsQ);
     INNR_TRY(c->q_row.ensure(Tq_pad * dim * sizeof(float)));
-    INNR_TRY(c->q_norm.ensure(Tq_pad * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(2 * Tq_pad * sizeof(float)));  // [Tq_pad] squared norms, [Tq_pad] 1/norm (MFMA engine)
     INNR_HIP_CHECK(hipMemsetAsync(c->q_row.p, 0, Tq_pad * dim * sizeof(float), c->stream));
     INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, qtok, Tq * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (cosine) {
@@ -1291,12 +1283,19 @@ static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok
                                                                                    (uint32_t)dim, c->q_norm.as<float>());
         INNR_HIP_CHECK(hipGetLastError());
     }
+    return INNR_OK;
+}
+
+// exact engine over `nslots` documents (all of them, or the ones listed in doc_ids) -> out[slot]; query staged
+static innr_status maxsim_scan_exact(innr_docs* d, int cosine, size_t Tq, const uint32_t* doc_ids, size_t nslots, float* out) {
+    innr_ctx* c = d->ctx;
+    const size_t dim = d->dim;
     uint32_t Tp = 1;
     while (Tp < d->T && Tp < 64) Tp <<= 1;
     const uint32_t docs_per_wave = 64 / Tp;
-    const size_t nwaves_needed = (d->ndocs + docs_per_wave - 1) / docs_per_wave;
-    const unsigned blocks = (unsigned)std::min<size_t>((nwaves_needed + 3) / 4, (size_t)c->num_cus * 2);
-    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * dim * sizeof(float)));  // packed copy of one pass of query tokens
+    const size_t nwaves_needed = (nslots + docs_per_wave - 1) / docs_per_wave;
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((nwaves_needed + 3) / 4, (size_t)c->num_cus * 2));
+    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));  // packed query (either engine)
     float* qpk = c->q_kmajor.as<float>();
     for (size_t p0 = 0; p0 < Tq; p0 += kMsQ) {
         const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
@@ -1309,12 +1308,12 @@ static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok
             maxsim_pack_query_kernel<<<(npk + 255) / 256, 256, 0, c->stream>>>(qp, NQV, (uint32_t)dim, qpk);            \
         if (d->T > 64)                                                                                                  \
             maxsim_scan_kernel<COSV, NQV, true><<<blocks, kMsThreads, 0, c->stream>>>(                                  \
-                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                 \
-                COSV ? aa : nullptr, out, out, p0 == 0);                                                                \
+                d->tok, d->doc_len, (uint32_t)nslots, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                   \
+                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids);                                                       \
         else                                                                                                            \
             maxsim_scan_kernel<COSV, NQV, false><<<blocks, kMsThreads, 0, c->stream>>>(                                 \
-                d->tok, d->doc_len, (uint32_t)d->ndocs, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                 \
-                COSV ? aa : nullptr, out, out, p0 == 0);                                                                \
+                d->tok, d->doc_len, (uint32_t)nslots, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                   \
+                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids);                                                       \
     } while (0)
         if (cosine) {
             if (nq <= 8) INNR_MS_LAUNCH(true, 8); else if (nq <= 16) INNR_MS_LAUNCH(true, 16); else INNR_MS_LAUNCH(true, 32);
@@ -1325,6 +1324,23 @@ static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok
         INNR_HIP_CHECK(hipGetLastError());
     }
     return INNR_OK;
+}
+
+// exact scores of every document into c->scores (device); q tokens uploaded from the host
+static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim) {
+    innr_ctx* c = d->ctx;
+    if (dim != d->dim) {  // maxsim.rs:103-110
+        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
+        return INNR_E_DIM_MISMATCH;
+    }
+    INNR_TRY(c->scores.ensure(std::max<size_t>(d->ndocs, 1) * sizeof(float)));
+    float* out = c->scores.as<float>();
+    if (Tq == 0 || d->T == 0 || d->ndocs == 0) {  // maxsim.rs:97-99: empty query or empty documents -> 0.0
+        INNR_HIP_CHECK(hipMemsetAsync(out, 0, std::max<size_t>(d->ndocs, 1) * sizeof(float), c->stream));
+        return INNR_OK;
+    }
+    INNR_TRY(maxsim_stage_query(d, cosine, qtok, Tq));
+    return maxsim_scan_exact(d, cosine, Tq, nullptr, d->ndocs, out);
 }
 
 innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, float* out) {
@@ -1338,32 +1354,11 @@ innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size
     return INNR_OK;
 }
 
-innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
-                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
-    if (stats) memset(stats, 0, sizeof(*stats));
-    if (!d || !out_k || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
-    *out_k = 0;
+// top-KP of the dense score array c->scores -> c->sel / c->sel_cnt (order: score desc, document index asc -- the
+// caller's stable sort in the reference example, examples/maxsim_colbert.rs:186-187)
+static innr_status maxsim_select(innr_docs* d, uint32_t KP) {
     innr_ctx* c = d->ctx;
-    INNR_TRY(bind_device(c));
-    if (dim != d->dim && Tq && d->T) {
-        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
-        return INNR_E_DIM_MISMATCH;
-    }
-    if (d->ndocs == 0 || k == 0) return INNR_OK;
-    const size_t kout = std::min(k, d->ndocs);
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
-    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
-    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    // exact top-k of the dense score array (stable order: score desc, doc index asc -- the caller's sort in the
-    // reference example, examples/maxsim_colbert.rs:186-187)
-    const uint32_t KP = pick_kp(kout, 0), cap = exact_cap(KP);
+    const uint32_t cap = exact_cap(KP);
     const size_t nchunks = (d->ndocs + 255) / 256;
     size_t nslots = round_up(std::min<size_t>(nchunks, (size_t)c->num_cus * 8), 4);
     const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
@@ -1380,13 +1375,164 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
         default: dense_filter_kernel<20><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
     }
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_TRY(run_select(c, lists, counts, (uint32_t)nslots, 1, cap, KP, 1));
+    return run_select(c, lists, counts, (uint32_t)nslots, 1, cap, KP, 1);
+}
+
+// per-token 1/norm and the corpus-wide maximum token norm, computed once per corpus (MFMA engine)
+static innr_status maxsim_ensure_token_norms(innr_docs* d) {
+    if (d->tok_inv) return INNR_OK;
+    innr_ctx* c = d->ctx;
+    const size_t ntok = d->ndocs * d->T;
+    hipError_t e = hipMalloc((void**)&d->tok_inv, std::max<size_t>(ntok, 1) * sizeof(float));
+    if (e != hipSuccess) {
+        d->tok_inv = nullptr;
+        set_error("hipMalloc(%zu bytes) for token norms failed: %s", ntok * sizeof(float), hipGetErrorString(e));
+        return INNR_E_OOM;
+    }
+    INNR_TRY(c->misc.ensure(4096));
+    INNR_HIP_CHECK(hipMemsetAsync(c->misc.p, 0, 4, c->stream));
+    maxsim_token_norms_kernel<<<(unsigned)((ntok + 255) / 256), 256, 0, c->stream>>>(d->tok, ntok, (uint32_t)d->dim, d->tok_inv,
+                                                                                     c->misc.as<uint32_t>());
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t bits = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&bits, c->misc.p, 4, hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(&d->max_norm, &bits, 4);
+    return INNR_OK;
+}
+
+static bool maxsim_mfma_eligible(const innr_docs* d, size_t Tq) {
+    return d->T > 16 && d->dim % 8 == 0 && d->dim >= 8 && d->dim <= 512 && Tq > 0 && d->ndocs > 0;
+}
+
+// MFMA engine: approximate scores of every document (c->scores), top-KP by approximate score, exact re-score of
+// those KP documents, proof. Results in c->out_idx / c->out_score; *proven = false -> the caller redoes it exactly.
+static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t kout, bool* proven,
+                                    uint32_t* kp_out) {
+    innr_ctx* c = d->ctx;
+    const size_t dim = d->dim;
+    *proven = false;
+    INNR_TRY(maxsim_ensure_token_norms(d));
+    if (!(d->max_norm - d->max_norm == 0.0f)) return INNR_OK;  // non-finite token somewhere: exact engine
+    // error bound of the approximate document score: per (token, query token) pair the MFMA fma chain
+    // and the reference's mul-then-add 4-way sum differ by <= (2 dim + 8) u |q_j| |d_i|; the max over tokens is
+    // 1-Lipschitz; the two 32-term sums (tree here, sequential there) add <= 2 Tq u sum_j |best_j|.
+    double qsum = 0.0;
+    for (size_t j = 0; j < Tq; ++j) {
+        double ss = 0.0;
+        for (size_t e = 0; e < dim; ++e) ss += (double)qtok[j * dim + e] * (double)qtok[j * dim + e];
+        qsum += std::sqrt(ss);
+    }
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double Ed = cosine ? 1.05 * (2.0 * dim + 32.0 + 2.0 * Tq) * u * (double)Tq
+                             : 1.05 * (2.0 * dim + 8.0 + 2.0 * Tq) * u * (double)d->max_norm * qsum;
+    if (!(Ed - Ed == 0.0) || Ed > 3.0e38) return INNR_OK;
+    const float E = (float)(Ed * 1.0000002);
+    INNR_TRY(maxsim_stage_query(d, cosine, qtok, Tq));
+    INNR_TRY(c->scores.ensure(d->ndocs * sizeof(float)));
+    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));
+    float* qB = c->q_kmajor.as<float>();
+    float* approx = c->scores.as<float>();
+    const size_t Tq_pad = round_up(Tq, kMsQ);
+    float* qscale = c->q_norm.as<float>() + Tq_pad;
+    if (cosine) {
+        maxsim_query_scale_kernel<<<(unsigned)((Tq_pad + 63) / 64), 64, 0, c->stream>>>(c->q_norm.as<float>(), (uint32_t)Tq_pad, qscale);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    const size_t lds = dim * 32 * sizeof(float);  // [dim/8][64][4]
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((d->ndocs + 3) / 4, (size_t)c->num_cus * 8));
+    for (size_t p0 = 0; p0 < Tq; p0 += kMsQ) {
+        const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
+        maxsim_pack_mfma_kernel<<<(unsigned)((dim * 32 + 255) / 256), 256, 0, c->stream>>>(c->q_row.as<float>() + p0 * dim,
+                                                                                          (uint32_t)dim, qB);
+        if (cosine)
+            maxsim_mfma_kernel<true><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, d->tok_inv, (uint32_t)d->ndocs,
+                                                                             (uint32_t)d->T, (uint32_t)dim, qB, nq, qscale + p0,
+                                                                             approx, approx, p0 == 0);
+        else
+            maxsim_mfma_kernel<false><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, nullptr, (uint32_t)d->ndocs,
+                                                                              (uint32_t)d->T, (uint32_t)dim, qB, nq, nullptr,
+                                                                              approx, approx, p0 == 0);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    const uint32_t KP = pick_kp(kout, 16);
+    *kp_out = KP;
+    INNR_TRY(maxsim_select(d, KP));
+    // exact re-score of the candidates, in the selection's order
+    INNR_TRY(c->misc.ensure(4096 + KP * (sizeof(uint32_t) + sizeof(float))));
+    uint32_t* ids = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 4096);
+    float* exact = reinterpret_cast<float*>(ids + KP);
+    maxsim_cand_ids_kernel<<<(KP + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), KP, ids);
+    INNR_HIP_CHECK(hipGetLastError());
+    const size_t ncand = std::min<size_t>(KP, d->ndocs);
+    INNR_TRY(maxsim_scan_exact(d, cosine, Tq, ids, ncand, exact));
     INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
-    emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, 1, (uint32_t)kout, false,
-                                                                              d->index_base, c->out_idx.as<uint64_t>(),
-                                                                              c->out_score.as<float>());
+    uint32_t* flag = c->flags.as<uint32_t>() + 64;
+    maxsim_finish_kernel<<<1, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), exact, (uint32_t)kout,
+                                                   (uint32_t)d->ndocs, E, d->index_base, c->out_idx.as<uint64_t>(),
+                                                   c->out_score.as<float>(), flag);
     INNR_HIP_CHECK(hipGetLastError());
+    uint32_t ok = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&ok, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *proven = ok != 0;
+    return INNR_OK;
+}
+
+innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
+                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!d || !out_k || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
+    if (engine != INNR_KNN_AUTO && engine != INNR_KNN_EXACT && engine != INNR_KNN_MFMA) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    innr_ctx* c = d->ctx;
+    INNR_TRY(bind_device(c));
+    if (dim != d->dim && Tq && d->T) {
+        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
+        return INNR_E_DIM_MISMATCH;
+    }
+    if (d->ndocs == 0 || k == 0) return INNR_OK;
+    const size_t kout = std::min(k, d->ndocs);
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
+    const bool eligible = maxsim_mfma_eligible(d, Tq) && pick_kp(kout, 16) <= 256;
+    if (engine == INNR_KNN_MFMA && !eligible) {
+        set_error("maxsim MFMA engine needs T > 16, dim %% 8 == 0, 8 <= dim <= 512, a non-empty query and k <= 240");
+        return INNR_E_UNSUPPORTED;
+    }
+    const bool use_mfma = engine == INNR_KNN_MFMA || (engine == INNR_KNN_AUTO && eligible && d->ndocs >= 4096);
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    bool proven = false;
+    uint32_t KP = 0;
+    int used = INNR_KNN_EXACT;
+    float scan_ms = 0.0f;
+    if (use_mfma) {
+        INNR_TRY(maxsim_topk_mfma(d, cosine, qtok, Tq, kout, &proven, &KP));
+        if (proven) {
+            used = INNR_KNN_MFMA;
+            (void)hipEventElapsedTime(&scan_ms, c->ev[2], c->ev[3]);
+        }
+    }
+    if (!proven) {
+        INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+        INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
+        INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+        KP = pick_kp(kout, 0);
+        INNR_TRY(maxsim_select(d, KP));
+        INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
+        INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
+        emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, 1, (uint32_t)kout,
+                                                                                  false, d->index_base, c->out_idx.as<uint64_t>(),
+                                                                                  c->out_score.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
     INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     INNR_TRY(check_errflag(c));
     INNR_HIP_CHECK(hipMemcpyAsync(out_doc, c->out_idx.p, kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -1394,10 +1540,12 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
     *out_k = kout;
     if (stats) {
-        stats->engine = INNR_KNN_EXACT;
+        stats->engine = used;
         stats->candidates_kept = KP;
+        stats->queries_fallback = (use_mfma && !proven) ? 1u : 0u;
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) stats->gemm_ms = ms;  // the scan kernel(s)
+        if (used == INNR_KNN_MFMA) stats->gemm_ms = scan_ms;  // the approximate scan kernel(s)
+        else if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) stats->gemm_ms = ms;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     return INNR_OK;

@@ -152,16 +152,17 @@ __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
     uint32_t dim, const float* __restrict__ qtok /*[NQ][dim], zero-padded*/,
     const float* __restrict__ qpk /*[dim/4][NQ][4] packed copy*/, uint32_t nq,
     const float* __restrict__ q_aa /*[nq] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
-    bool first_pass) {
+    bool first_pass, const uint32_t* __restrict__ doc_ids /*null: slot s is document s; else document doc_ids[s]*/) {
     const int lane = threadIdx.x & 63;
     const uint32_t docs_per_wave = 64 / Tp;
     const uint32_t wave = (blockIdx.x * kMsThreads + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
     const uint32_t chunks = dim / 4;
     for (uint32_t dbase = wave * docs_per_wave; dbase < ndocs; dbase += nwaves * docs_per_wave) {
-        const uint32_t doc = dbase + lane / Tp;
+        const uint32_t slot = dbase + lane / Tp;  // output position; ndocs = number of slots
+        const uint32_t doc = (slot < ndocs && doc_ids) ? doc_ids[slot] : slot;
         const uint32_t t = lane % Tp;
-        const uint32_t len = (doc < ndocs) ? (doc_len ? min(doc_len[doc], T) : T) : 0;
+        const uint32_t len = (slot < ndocs) ? (doc_len ? min(doc_len[doc], T) : T) : 0;
         // documents with T > 64 tokens: walk the tokens in groups of Tp = 64, keeping a running max per query token
         float best[NQ];
 #pragma unroll
@@ -228,12 +229,12 @@ __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
             }
         }
         // sum over query tokens in token order, folded from -0.0 (first pass) or from the previous passes' total
-        if (t == 0 && doc < ndocs) {
-            float total = first_pass ? -0.0f : partial_in[doc];
+        if (t == 0 && slot < ndocs) {
+            float total = first_pass ? -0.0f : partial_in[slot];
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi)
                 if ((uint32_t)qi < nq) total = ex::add(total, best[qi]);
-            out[doc] = (len == 0) ? 0.0f : total;  // empty document -> 0.0 (maxsim.rs:97-99)
+            out[slot] = (len == 0) ? 0.0f : total;  // empty document -> 0.0 (maxsim.rs:97-99)
         }
     }
 }
@@ -250,6 +251,175 @@ __global__ void query_token_sq_kernel(const float* __restrict__ qtok, uint32_t n
     float r = ex::add(ex::add(ex::add(s[0], s[1]), s[2]), s[3]);
     for (uint32_t d = chunks * 4; d < dim; ++d) r = ex::mad2(r, a[d], a[d]);
     aa[i] = r;
+}
+
+// ---- MFMA engine: approximate scores of every document, then exact re-score of the best (api.hip) ---------------
+// D[i][j] = sum_k A[i][k] B[k][j] on v_mfma_f32_32x32x2_f32 with A = 32 document tokens (rows i), B = 32 query tokens
+// (columns j). Lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] and receives column j = l&31, rows
+// i = (g&3) + 8(g>>2) + 4(l>>5), g = 0..15: the max over document tokens is an in-lane max over the 16 accumulator
+// registers plus one exchange between the wave halves; the sum over query tokens is a 32-lane reduction.
+// K order: the sum over dimensions is order-free here, so dimension 8c + 4h + e is K-step (4c + e), half h: every
+// lane loads ONE float4 (16 B) of its token row per 8 dimensions, and a token's 128-B line is consumed by 4
+// consecutive loads of lanes i and i+32. Query operands wait in LDS in exactly that order (one ds_read_b128 per 4
+// MFMAs). Requires dim % 8 == 0.
+typedef float msf32x16 __attribute__((ext_vector_type(16)));
+
+// qB[(c*64 + l)*4 + e] = q[j = l&31][8c + 4(l>>5) + e]; rows j >= nq are zero in qtok (padded buffer)
+__global__ void maxsim_pack_mfma_kernel(const float* __restrict__ qtok, uint32_t dim, float* __restrict__ qB) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dim * 32) return;
+    const uint32_t e = i & 3, l = (i >> 2) & 63, c = i >> 8;
+    qB[i] = qtok[(size_t)(l & 31) * dim + 8 * c + 4 * (l >> 5) + e];
+}
+
+// per token: bb = sum of squares in cosine_portable's order (dense.rs:288-339), inv[t] = bb > eps^2 ? 1/sqrt(bb) : 0
+// (the reference's zero-norm guard, dense.rs:341-345) and the corpus-wide maximum of sqrt(bb) (as uint bits: norms
+// are non-negative, NaN compares above everything and poisons the maximum on purpose)
+__global__ void maxsim_token_norms_kernel(const float* __restrict__ tok, size_t ntok, uint32_t dim, float* __restrict__ inv,
+                                          uint32_t* __restrict__ max_bits) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float nrm = 0.0f;
+    if (r < ntok) {
+        const float* a = tok + r * dim;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        const uint32_t chunks = dim / 4;
+        for (uint32_t c = 0; c < chunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(a + 4 * c);
+            s4[0] = ex::mad2(s4[0], v.x, v.x);
+            s4[1] = ex::mad2(s4[1], v.y, v.y);
+            s4[2] = ex::mad2(s4[2], v.z, v.z);
+            s4[3] = ex::mad2(s4[3], v.w, v.w);
+        }
+        float bb = ex::add(ex::add(ex::add(s4[0], s4[1]), s4[2]), s4[3]);
+        for (uint32_t d = chunks * 4; d < dim; ++d) bb = ex::mad2(bb, a[d], a[d]);
+        constexpr float kEpsSq = INNR_NORM_EPSILON * INNR_NORM_EPSILON;
+        nrm = ex::sqrt(bb);
+        inv[r] = (bb > kEpsSq) ? ex::div(1.0f, nrm) : 0.0f;
+    }
+    uint32_t m = __float_as_uint(nrm);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_bits, m);
+}
+
+// COS: q_scale[j] = aa_j > eps^2 ? 1/sqrt(aa_j) : 0 from the exact squared norms of the query tokens
+__global__ void maxsim_query_scale_kernel(const float* __restrict__ aa, uint32_t n, float* __restrict__ scale) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr float kEpsSq = INNR_NORM_EPSILON * INNR_NORM_EPSILON;
+    scale[i] = (aa[i] > kEpsSq) ? ex::div(1.0f, ex::sqrt(aa[i])) : 0.0f;
+}
+
+template <bool COS>
+__global__ __launch_bounds__(kMsThreads) void maxsim_mfma_kernel(
+    const float* __restrict__ tok, const uint32_t* __restrict__ doc_len, const float* __restrict__ tok_inv /*COS*/,
+    uint32_t ndocs, uint32_t T, uint32_t dim, const float* __restrict__ qB /*[dim/8][64][4]*/, uint32_t nq,
+    const float* __restrict__ q_scale /*[32] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
+    bool first_pass) {
+    extern __shared__ __attribute__((aligned(16))) float s_qB[];
+    const int lane = threadIdx.x & 63;
+    const uint32_t nch = dim / 8;
+    for (uint32_t i = threadIdx.x; i < nch * 64; i += kMsThreads)
+        reinterpret_cast<float4*>(s_qB)[i] = reinterpret_cast<const float4*>(qB)[i];
+    __syncthreads();
+    const float4* bl = reinterpret_cast<const float4*>(s_qB) + lane;
+    const uint32_t wave = (blockIdx.x * kMsThreads + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
+    const uint32_t j = lane & 31, h = lane >> 5;
+    const float qs = COS ? q_scale[j] : 1.0f;
+    for (uint32_t doc = wave; doc < ndocs; doc += nwaves) {  // wave-uniform
+        const uint32_t len = doc_len ? min(doc_len[doc], T) : T;
+        float best = -INFINITY;  // max over this document's tokens of (token . query token j)
+        for (uint32_t t0 = 0; t0 < len; t0 += 32) {
+            // rows past the document's end re-read its last token (mapped memory) and are masked out of the max
+            const uint32_t r = min(t0 + j, T - 1);
+            const float* rowp = tok + ((size_t)doc * T + r) * dim + 4 * h;
+            msf32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+            float4 a[4], an[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((uint32_t)u < nch) a[u] = *reinterpret_cast<const float4*>(rowp + 8 * u);
+            for (uint32_t cb = 0; cb < nch; cb += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cb + 4 + u < nch) an[u] = *reinterpret_cast<const float4*>(rowp + 8 * (cb + 4 + u));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (cb + u < nch) {
+                        const float4 b4 = bl[(size_t)(cb + u) * 64];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b4.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b4.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b4.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b4.w, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = an[u];
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const uint32_t row = t0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                float v = acc[g];
+                if (COS) v *= tok_inv[(size_t)doc * T + min(row, T - 1)];
+                m = (row < len) ? fmaxf(m, v) : m;
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            best = fmaxf(best, m);
+        }
+        float v = (j < nq) ? best * qs : 0.0f;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) {
+            float total = (first_pass ? 0.0f : partial_in[doc]) + v;
+            if (total != total) total = INFINITY;  // a NaN anywhere: force the document into the exact re-score
+            out[doc] = (len == 0) ? 0.0f : total;
+        }
+    }
+}
+
+// Re-score epilogue (one block of 256 threads, ncand <= 256): order the candidates by (exact score desc, document
+// index asc), emit the best kout, and PROVE them: every document outside the candidate set has approximate score
+// <= t_approx (the worst candidate's), hence exact score <= t_approx + E; if the kout-th exact score is strictly
+// above that, no outsider belongs in the answer. flag[0] = 1 when proven (or when every document was a candidate).
+__global__ __launch_bounds__(256) void maxsim_finish_kernel(const uint64_t* __restrict__ sel /*approx composites, best first*/,
+                                                            const uint32_t* __restrict__ sel_cnt, const float* __restrict__ exact,
+                                                            uint32_t kout, uint32_t ndocs, float E, uint64_t index_base,
+                                                            uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
+                                                            uint32_t* __restrict__ flag) {
+    __shared__ uint64_t s_c[256];
+    __shared__ float s_kth;
+    const uint32_t n = min(sel_cnt[0], 256u), t = threadIdx.x;
+    uint64_t mine = 0;
+    if (t < n) mine = cand_make(f32_ord(exact[t]), cand_idx(sel[t]));
+    s_c[t] = mine;
+    __syncthreads();
+    if (t < n) {
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < n; ++o) rank += s_c[o] > mine;
+        if (rank < kout) {
+            out_idx[rank] = index_base + cand_idx(mine);
+            out_score[rank] = exact[t];
+            if (rank == kout - 1) s_kth = exact[t];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        bool ok = n >= kout;
+        if (ok && n < ndocs) {
+            const float t_approx = pref_score(cand_pref(sel[n - 1]), false);
+            const float bound = t_approx + E;
+            ok = (s_kth - s_kth == 0.0f) && (bound - bound == 0.0f) && s_kth > bound;
+        }
+        flag[0] = ok ? 1u : 0u;
+    }
+}
+
+// candidate document ids (uint32) from the selected composites
+__global__ void maxsim_cand_ids_kernel(const uint64_t* __restrict__ sel, const uint32_t* __restrict__ sel_cnt, uint32_t KP,
+                                       uint32_t* __restrict__ ids) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < KP) ids[t] = (t < sel_cnt[0]) ? cand_idx(sel[t]) : 0u;
 }
 
 // synthetic documents: token (doc, t) = generate_normalized-style row of the uniform stream:

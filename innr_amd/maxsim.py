@@ -105,7 +105,9 @@ class DocumentCorpus:
                                         C.c_void_p(out.ctypes.data) if out.size else None))
         return out
 
-    def topk(self, query_tokens, k: int, cosine: bool = False, stats: Optional[KnnStats] = None):
+    def topk(self, query_tokens, k: int, cosine: bool = False, stats: Optional[KnnStats] = None,
+             engine: int = _lib.KNN_AUTO):
+        """k best documents (index, exact maxsim score), best first; engine KNN_EXACT / KNN_MFMA / KNN_AUTO."""
         q = self._q(query_tokens)
         kk = max(min(int(k), self._n), 1)
         idx = np.empty(kk, dtype=np.uint64)
@@ -113,7 +115,7 @@ class DocumentCorpus:
         out_k = C.c_size_t(0)
         st = stats if stats is not None else KnnStats()
         check(load().innr_maxsim_topk(self._h, 1 if cosine else 0, C.c_void_p(q.ctypes.data) if q.size else None,
-                                      q.shape[0], self._dim if q.size == 0 else q.shape[1], int(k),
+                                      q.shape[0], self._dim if q.size == 0 else q.shape[1], int(k), int(engine),
                                       C.c_void_p(idx.ctypes.data), C.c_void_p(sc.ctypes.data), C.byref(out_k), C.byref(st)))
         r = int(out_k.value)
         return idx[:r].copy(), sc[:r].copy()

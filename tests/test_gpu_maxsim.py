@@ -93,16 +93,76 @@ def test_maxsim_generated_corpus_matches_oracle_generator(M):
     assert bits_equal(dc.scores(q), _oracle_scores(q, toks))
 
 
+@pytest.mark.parametrize("ndocs,T,dim,Tq,k", [(500, 64, 128, 32, 10), (3000, 32, 64, 8, 100), (2000, 17, 8, 1, 5),
+                                              (1200, 100, 96, 40, 30), (900, 70, 48, 70, 240), (300, 64, 512, 3, 7)])
+def test_maxsim_mfma_engine_matches_oracle(M, ndocs, T, dim, Tq, k):
+    import innr_amd
+    toks = _tokens(ndocs, T, dim, 21)
+    lens = np.array([max(1, (i * 13) % (T + 1)) for i in range(ndocs)], dtype=np.uint32)
+    lens[::7] = T
+    q = _tokens(1, Tq, dim, 17)[0]
+    for dl in (None, lens):
+        dc = M.DocumentCorpus.from_tokens(toks, dl)
+        for cosine in (False, True):
+            sc = _oracle_scores(q, toks, dl, cosine=cosine)
+            order = np.argsort(-sc.astype(np.float64), kind="stable")[:k]
+            st = innr_amd.KnnStats()
+            idx, s = dc.topk(q, k, cosine=cosine, engine=innr_amd.KNN_MFMA, stats=st)
+            assert idx.tolist() == order.tolist() and bits_equal(s, sc[order]), (dl is None, cosine)
+            assert st.engine == innr_amd.KNN_MFMA and st.queries_fallback == 0, (dl is None, cosine, st.engine)
+
+
+def test_maxsim_mfma_engine_unnormalised_ties_and_nonfinite(M):
+    import innr_amd
+    ndocs, T, dim, Tq, k = 800, 40, 64, 12, 20
+    toks = (_tokens(ndocs, T, dim, 2) * np.float32(7.25)).astype(np.float32)
+    toks[11, 3, :] = 0.0
+    q = (_tokens(1, Tq, dim, 9)[0] * np.float32(0.3)).astype(np.float32)
+    q[4, :] = 0.0  # zero query token: contributes max = 0 under cosine
+    dc = M.DocumentCorpus.from_tokens(toks)
+    for cosine in (False, True):
+        sc = _oracle_scores(q, toks, cosine=cosine)
+        order = np.argsort(-sc.astype(np.float64), kind="stable")[:k]
+        idx, s = dc.topk(q, k, cosine=cosine, engine=innr_amd.KNN_MFMA)
+        assert idx.tolist() == order.tolist() and bits_equal(s, sc[order])
+    # an exact tie across the cut cannot be proven: the engine must fall back and still return the stable order
+    best = int(np.argmax(_oracle_scores(q, toks)))
+    toks2 = toks.copy()
+    for i in range(100, 140):  # more copies of the best document than the engine keeps candidates (KP = 32)
+        toks2[i] = toks2[best]
+    dc2 = M.DocumentCorpus.from_tokens(toks2)
+    sc = _oracle_scores(q, toks2)
+    st = innr_amd.KnnStats()
+    idx, s = dc2.topk(q, 1, engine=innr_amd.KNN_MFMA, stats=st)
+    assert idx.tolist() == [int(np.argsort(-sc.astype(np.float64), kind="stable")[0])] and bits_equal(s, sc[idx.astype(int)])
+    assert st.queries_fallback == 1 and st.engine == innr_amd.KNN_EXACT
+    # a non-finite token anywhere: the error bound is void, AUTO and MFMA requests both end on the exact engine
+    toks3 = toks.copy()
+    toks3[5, 1, 2] = np.inf
+    toks3[6, 0, 0] = np.nan
+    dc3 = M.DocumentCorpus.from_tokens(toks3)
+    sc = dc3.scores(q)
+    idx, s = dc3.topk(q, k, engine=innr_amd.KNN_MFMA, stats=st)
+    finite = np.where(np.isnan(sc), -np.inf, sc).astype(np.float64)
+    # NaN document scores order as total_cmp does (+NaN first); compare on the finite part only
+    got_finite = [i for i in idx.tolist() if not np.isnan(sc[i])]
+    want = [i for i in np.argsort(-finite, kind="stable").tolist() if not np.isnan(sc[i])][:len(got_finite)]
+    assert got_finite == want and st.engine == innr_amd.KNN_EXACT
+    with pytest.raises(innr_amd.InnrError):
+        M.DocumentCorpus.from_tokens(_tokens(10, 8, 16, 1)).topk(_tokens(1, 2, 16, 1)[0], 2, engine=innr_amd.KNN_MFMA)  # T <= 16
+
+
 def test_maxsim_c4_shape_properties(M):
     # BASELINE.json configs[3] at 1/10 scale for the oracle cross-check (100K docs x 64 x 128, 32-token query, top-100)
     import innr_amd
     ndocs, T, dim, Tq, k = 100_000, 64, 128, 32, 100
     dc = M.DocumentCorpus.generate(ndocs, T, dim, seed=0)
     q = _tokens(1, Tq, dim, 123)[0]
-    st = innr_amd.KnnStats()
-    idx, sc = dc.topk(q, k, stats=st)
     allsc = dc.scores(q)
     order = np.argsort(-allsc.astype(np.float64), kind="stable")[:k]
-    assert idx.tolist() == order.tolist() and bits_equal(sc, allsc[order])
-    print(f"maxsim 100Kx64x128 Tq=32: scan {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms -> "
-          f"{ndocs*T*dim*4/st.gemm_ms/1e6:.0f} GB/s")
+    for name, eng in (("exact", innr_amd.KNN_EXACT), ("mfma", innr_amd.KNN_MFMA), ("mfma", innr_amd.KNN_MFMA)):
+        st = innr_amd.KnnStats()
+        idx, sc = dc.topk(q, k, stats=st, engine=eng)
+        assert idx.tolist() == order.tolist() and bits_equal(sc, allsc[order])
+        print(f"maxsim 100Kx64x128 Tq=32 {name}: scan {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms -> "
+              f"{ndocs*T*dim*4/st.gemm_ms/1e6:.0f} GB/s, engine {st.engine} fallback {st.queries_fallback}")

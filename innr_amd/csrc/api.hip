@@ -84,6 +84,7 @@ struct innr_batch {
     float* V = nullptr;      // [Dpad][ldN]
     float* norms = nullptr;  // [ldN], lazily computed (exact batch_norms)
     float* invn = nullptr;   // [ldN], 1/norm (0 for zero-norm vectors): GEMM engine's approximate cosine
+    float* sqn = nullptr;    // [ldN], norm^2: GEMM engine's approximate L2
     uint32_t* max_norm_bits = nullptr;
     bool norms_ready = false;
     float max_norm = 0.0f;
@@ -384,14 +385,24 @@ static innr_status prep_queries(innr_batch* b, const GemmPlan& p, const float* d
     return INNR_OK;
 }
 
+static innr_status ensure_sqnorms(innr_batch* b) {
+    INNR_TRY(ensure_norms(b));
+    if (b->sqn) return INNR_OK;
+    INNR_HIP_CHECK(hipMalloc((void**)&b->sqn, b->ldN * sizeof(float)));
+    sq_norms_kernel<<<(unsigned)((b->ldN + 255) / 256), 256, 0, b->ctx->stream>>>(b->norms, b->ldN, b->N, b->sqn);
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
 static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* /*dQn*/,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
                             float* gemm_ms) {
     innr_ctx* c = b->ctx;
-    const bool cos = metric == INNR_METRIC_COSINE;
+    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     const GemmPlan p = plan_gemm(b, Q, kout);
-    INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot error bound
+    INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
     if (cos) INNR_TRY(ensure_invnorms(b));
+    if (l2) INNR_TRY(ensure_sqnorms(b));
     INNR_TRY(prep_queries(b, p, dQ, Q, cos));
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
@@ -400,29 +411,44 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     float* invq = c->misc.as<float>();
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+    float* Cj = nullptr;
+    if (l2) {  // epilogue constants C_j - |q_j|^2 (in invq's place) and C_j (for the proof)
+        INNR_TRY(c->tmp_norms.ensure(p.Qpad * sizeof(float)));
+        Cj = c->tmp_norms.as<float>();
+        l2_query_consts_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, Q,
+                                                                                       b->max_norm, invq, Cj);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
 
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
     if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0)));
+    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0)));
     else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
                         (uint32_t)Q));
 
-    // |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum
+    // dot / cosine: |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum.
+    // L2: approx = C - (|v|^2 - 2 q.v + |q|^2) assembled from the MFMA dot (<= (2D+8) u |q||v|, doubled), the squared
+    // cached norms and the query norm (<= (D+4) u each, relative to their own size), three epilogue roundings, and the
+    // reference's own direct-difference sum is within (D+2) u of the true distance: every term is <= C = (|q|+max|v|)^2,
+    // so |(C - approx) - exact| <= (6D+40) u C with room to spare.
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
-    const float err_scale = cos ? cdu : cdu * b->max_norm;
-#define INNR_RESCORE(COSV, RKV)                                                                                     \
-    rescore_kernel<COSV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,          \
-                                                                 c->q_norm.as<float>(), c->sel.as<uint64_t>(),      \
+    const float err_scale = l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm);
+#define INNR_RESCORE(METV, RKV)                                                                                     \
+    rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,          \
+                                                                 c->q_norm.as<float>(), Cj, c->sel.as<uint64_t>(),  \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout,   \
                                                                  err_scale, b->index_base, d_out_idx, d_out_score,  \
                                                                  fallback)
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
-        if (rk == 1) INNR_RESCORE(true, 1); else if (rk == 2) INNR_RESCORE(true, 2); else INNR_RESCORE(true, 4);
+        if (rk == 1) INNR_RESCORE(1, 1); else if (rk == 2) INNR_RESCORE(1, 2); else INNR_RESCORE(1, 4);
+    } else if (l2) {
+        if (rk == 1) INNR_RESCORE(2, 1); else if (rk == 2) INNR_RESCORE(2, 2); else INNR_RESCORE(2, 4);
     } else {
-        if (rk == 1) INNR_RESCORE(false, 1); else if (rk == 2) INNR_RESCORE(false, 2); else INNR_RESCORE(false, 4);
+        if (rk == 1) INNR_RESCORE(0, 1); else if (rk == 2) INNR_RESCORE(0, 2); else INNR_RESCORE(0, 4);
     }
 #undef INNR_RESCORE
     INNR_HIP_CHECK(hipGetLastError());
@@ -635,6 +661,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->C8) (void)hipFree(b->C8);
     if (b->norms) (void)hipFree(b->norms);
     if (b->invn) (void)hipFree(b->invn);
+    if (b->sqn) (void)hipFree(b->sqn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
     delete b;
 }
@@ -806,11 +833,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
-    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && metric != INNR_METRIC_L2SQ) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
-    if (engine == INNR_KNN_MFMA && metric == INNR_METRIC_L2SQ) {
-        set_error("MFMA engine does not implement L2SQ yet; use INNR_KNN_EXACT/AUTO");
-        return INNR_E_UNSUPPORTED;
-    }
+    if (engine == INNR_KNN_AUTO) engine = (Q >= 16) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     const float* dQn = nullptr;

@@ -87,10 +87,13 @@ __device__ __forceinline__ void wait_but_last() { asm volatile("s_waitcnt vmcnt(
 __device__ __forceinline__ void wait_but_last5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 __device__ __forceinline__ void wait_but_last4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 
-enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2 };
+enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 
 // KIND kGemmDot: score = q.v            (batch_knn_dot)
 //      kGemmCos: score = q.v * invn[i] * invq[j]   (approximate cosine; exact one in the re-score)
+//      kGemmL2 : score = 2 q.v + invq[j] - invn[i] with invn[i] = |v_i|^2 and invq[j] = C_j - |q_j|^2, i.e.
+//                C_j - |q_j - v_i|^2 up to rounding: larger = closer, and non-negative for C_j = (|q_j| + max|v|)^2 so
+//                the raw-bit fast reject stays valid (batch_knn; exact direct-difference distance in the re-score)
 //      kGemmU8 : the corpus is u8 codes C[d*ldN + i] (scalar.rs): a tile stage is 16 x 128 BYTES (2 DMA pieces per
 //                block instead of 8), fragments are widened u8 -> f32 in registers (v_cvt_f32_ubyte0..3: one
 //                ds_read_b32 feeds the four row tiles) and score = scale * (q.c) + invq[j]   (invq = offset*sum(q)):
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
+    constexpr bool L2K = KIND == kGemmL2;
     const float* V = static_cast<const float*>(Vraw);
     const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
     __shared__ GemmLds s;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
                 int32_t best[2] = {INT32_MIN, INT32_MIN};
                 float iq[2] = {1.0f, 1.0f};
-                if (COS || U8) {  // COS: 1/||q||; U8: offset * sum(q)
+                if (COS || U8 || L2K) {  // COS: 1/||q||; U8: offset * sum(q); L2: C_j - |q_j|^2
                     iq[0] = invq[q0 + 64 * w + 2 * C + 0];
                     iq[1] = invq[q0 + 64 * w + 2 * C + 1];
                 }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
 #pragma unroll
                     for (int g3 = 0; g3 < 4; ++g3) {
                         float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // 1/||v|| of corpus rows 4*(g3 + ...) + rt
-                        if (COS) {
+                        if (COS || L2K) {
                             const float4 t = p[g3];
                             sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
                         }
@@ -332,6 +336,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                                 }
                                 if (U8) {
                                     v = v * scale + iq[ct];
+                                    acc[rt][ct][4 * gq + g3] = v;
+                                }
+                                if (L2K) {
+                                    v = (2.0f * v + iq[ct]) - sc[rt];
                                     acc[rt][ct][4 * gq + g3] = v;
                                 }
                                 const int32_t raw = (int32_t)__float_as_uint(v);
@@ -464,19 +472,23 @@ __global__ void inv_qnorms_kernel(const float* __restrict__ x, size_t n, size_t 
 //   best kout are written. Proof obligation for "no vector outside the candidate set can belong to the true
 //   top-k": every outsider has approx <= T (the KP-th approximate score) and |approx - exact| <= E, so it is
 //   enough that exact(k-th best candidate) > T + E. Failing queries are flagged for the exact engine.
-template <bool COS, int RK>
+// MET: 0 dot, 1 cosine, 2 squared L2 (direct differences, batch.rs:262-263; smaller is better; qaux[q] = C_q of the
+// GEMM epilogue, err_scale * C_q bounds |C_q - approx - exact distance|).
+template <int MET, int RK>
 __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V, size_t ldN, uint32_t D,
                                                      const float* __restrict__ Qm, const float* __restrict__ norms,
-                                                     const float* __restrict__ qnorm, const uint64_t* __restrict__ sel,
+                                                     const float* __restrict__ qnorm, const float* __restrict__ qaux,
+                                                     const uint64_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ sel_cnt, uint32_t KP, uint32_t kout,
                                                      float err_scale, uint64_t index_base,
                                                      uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                      uint32_t* __restrict__ fallback) {
+    constexpr bool COS = MET == 1, L2 = MET == 2;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
     const float* qv = Qm + (size_t)q * D;
-    const float qn = qnorm[q];
+    const float qn = L2 ? 0.0f : qnorm[q];
     uint64_t e[RK];
 #pragma unroll
     for (int r = 0; r < RK; ++r) {
@@ -486,13 +498,21 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
             const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
             const float* col = V + i;
             float acc = 0.0f;
+            if (L2) {
 #pragma unroll 8
-            for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
+                for (uint32_t d = 0; d < D; ++d) {
+                    const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
+                    acc = ex::mad2(acc, diff, diff);
+                }
+            } else {
+#pragma unroll 8
+                for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
+            }
             if (COS) {
                 const float vn = norms[i];
                 acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
             }
-            e[r] = cand_make(f32_ord(acc), i);
+            e[r] = cand_make(score_pref<L2>(acc), i);
         }
     }
     uint32_t rank[RK];
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
         const uint32_t c = r * 64 + lane;
         if (c < cnt && rank[r] < kout) {
             out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
-            out_score[(size_t)q * kout + rank[r]] = ord_f32(cand_pref(e[r]));
+            out_score[(size_t)q * kout + rank[r]] = pref_score(cand_pref(e[r]), L2);
         }
         if (c < cnt && rank[r] == kout - 1) {
             kth_bits = cand_pref(e[r]);
@@ -526,12 +546,41 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
     // margin proof (one lane holds the k-th best exact score)
     bool bad = false;
     if (have_kth && cnt == KP) {  // cnt < KP: every corpus vector is a candidate, nothing to prove
-        const float exact_k = ord_f32(kth_bits);
+        const float exact_k = pref_score(kth_bits, L2);
         const float T = ord_f32(cand_pref(sel[(size_t)q * KP + KP - 1]));
-        const float E = COS ? err_scale : err_scale * qn;
-        bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
+        if (L2) {
+            // outsiders: approx <= T, i.e. their approximate distance C - approx >= C - T, exact >= C - T - E
+            const float Cq = qaux[q];
+            bad = !(exact_k < (Cq - T) - err_scale * Cq);
+        } else {
+            const float E = COS ? err_scale : err_scale * qn;
+            bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
+        }
     }
     if (__any(bad) && lane == 0) fallback[q] = 1;
+}
+
+// L2 on the GEMM engine: per query C_j = (|q_j| + max|v|)^2 and the epilogue constant C_j - |q_j|^2 (padded queries: 0)
+__global__ void l2_query_consts_kernel(const float* __restrict__ qnorm, size_t Qpad, size_t Q, float max_norm,
+                                       float* __restrict__ cq, float* __restrict__ Cj) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Qpad) return;
+    float C = 0.0f, c = 0.0f;
+    if (j < Q) {
+        const float qn = qnorm[j], s = qn + max_norm;
+        C = s * s;
+        c = C - qn * qn;
+    }
+    cq[j] = c;
+    if (j < Q) Cj[j] = C;
+}
+
+// |v_i|^2 from the cached exact norms (padding rows: 0)
+__global__ void sq_norms_kernel(const float* __restrict__ norms, size_t ldN, size_t N, float* __restrict__ sq) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldN) return;
+    const float v = (i < N) ? norms[i] : 0.0f;
+    sq[i] = v * v;
 }
 
 }  // namespace innr

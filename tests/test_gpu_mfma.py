@@ -43,7 +43,7 @@ def _mfma_knn_checked(B, innr, metric, rows, data, qs, k, max_fallback):
     """MFMA engine == oracle, AND the GEMM path itself did the work (few/no exact-engine fallbacks)."""
     vb = _check_knn(B, innr, metric, rows, data, qs, k, innr.KNN_MFMA)
     st = innr.KnnStats()
-    fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi}[metric]
+    fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
     fn(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
     assert st.engine == innr.KNN_MFMA and st.queries_fallback <= max_fallback, st.queries_fallback
     return vb
@@ -80,14 +80,14 @@ def test_gemm_layout_asymmetric_integers(B, innr):
 
 
 # ------------------------------------------------------------------------------- kNN parity
-@pytest.mark.parametrize("metric", ["dot", "cos"])
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
 def test_knn_mfma_c1_shape(B, innr, metric):
     # BASELINE.json configs[0] shape (10K x 128, 100 queries, k = 10) on the GEMM engine, uniform data
     rows, data = _corpus(10_000, 128, 0, uniform=True)
     _mfma_knn_checked(B, innr, metric, rows, data, _queries(100, 128, uniform=True), 10, max_fallback=1)
 
 
-@pytest.mark.parametrize("metric", ["dot", "cos"])
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
 def test_knn_mfma_c1_example_generator(B, innr, metric):
     # the reference example's own LCG data (examples/batch_demo.rs:167-170): a one-parameter family with seas of
     # near-ties, so most margin proofs fail and those queries are redone on the exact engine. Results must
@@ -101,7 +101,7 @@ def test_knn_mfma_c1_example_generator(B, innr, metric):
 def test_knn_mfma_ragged(B, innr, n, dim, nq, k):
     rows, data = _corpus(n, dim, 77, uniform=True)
     vb = None
-    for metric in ("dot", "cos"):
+    for metric in ("dot", "cos", "l2"):
         vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(nq, dim, 4242, uniform=True), k,
                         innr.KNN_MFMA)
 
@@ -112,6 +112,7 @@ def test_knn_mfma_many_tiles_and_compactions(B, innr):
     qs = _queries(40, 32, 99, uniform=True)
     _mfma_knn_checked(B, innr, "dot", rows, data, qs, 10, max_fallback=2)
     _mfma_knn_checked(B, innr, "cos", rows, data, qs, 100, max_fallback=2)
+    _mfma_knn_checked(B, innr, "l2", rows, data, qs, 10, max_fallback=2)
 
 
 def test_knn_mfma_ties_zero_query_and_stats(B, innr):
@@ -119,7 +120,7 @@ def test_knn_mfma_ties_zero_query_and_stats(B, innr):
     rows = np.concatenate([base, base, base[::-1]])  # every vector three times: exact ties at every rank
     data = oracle.from_rows(rows)
     qs = np.concatenate([_queries(20, 24, 31, uniform=True), np.zeros((1, 24), np.float32)])
-    for metric in ("dot", "cos"):
+    for metric in ("dot", "cos", "l2"):
         _check_knn(B, innr, metric, rows, data, qs, 12, innr.KNN_MFMA)
     vb = B.VerticalBatch.from_rows(rows)
     st = innr.KnnStats()
@@ -143,6 +144,11 @@ def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
     for j, q in enumerate(qs):
         oi, os_ = oracle.batch_knn_dot(q, data, 5)
         assert same_knn("dot", idx[j], sc[j], oi, os_)
+    idx, sc = B.batch_knn_multi(qs, vb, 5, engine=innr.KNN_MFMA, stats=st)
+    assert st.queries_fallback == len(qs)
+    for j, q in enumerate(qs):
+        oi, os_ = oracle.batch_knn(q, data, 5)
+        assert same_knn("l2", idx[j], sc[j], oi, os_)
 
 
 def test_knn_auto_engine_selection(B, innr):
@@ -152,8 +158,8 @@ def test_knn_auto_engine_selection(B, innr):
     assert st.engine == innr.KNN_EXACT
     B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
     assert st.engine == innr.KNN_MFMA
-    B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)  # L2 stays on the exact engine
-    assert st.engine == innr.KNN_EXACT
+    B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_MFMA and st.queries_fallback <= 1
 
 
 # ------------------------------------------------------------------------------- larger sizes: engine agreement
@@ -162,7 +168,7 @@ def test_engines_agree_1m(B, innr):
     # so agreement of the two engines carries parity to this size.
     vb = B.VerticalBatch.generate(1_000_000, 128, 0)
     qs = _queries(256, 128, 10_000_000, uniform=True)
-    for fn in (B.batch_knn_dot_multi, B.batch_knn_cosine_multi):
+    for fn in (B.batch_knn_dot_multi, B.batch_knn_cosine_multi, B.batch_knn_multi):
         st = innr.KnnStats()
         i1, s1 = fn(qs, vb, 10, engine=innr.KNN_MFMA, stats=st)
         i2, s2 = fn(qs[:64], vb, 10, engine=innr.KNN_EXACT)
@@ -200,3 +206,10 @@ def test_full_size_properties_c2(B, innr):
     assert np.array_equal(idx[:16], i2) and bits_equal(sc[:16], s2)
     assert np.all(sc[:, :-1] >= sc[:, 1:]) and st.queries_fallback <= 4
     print(f"C2 dot: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")
+    # batch_knn (squared L2) on the GEMM engine: row r is its own nearest neighbour at distance 0
+    idx, sc = B.batch_knn_multi(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+    assert np.array_equal(idx[:, 0].astype(np.int64), picks) and np.all(sc[:, 0] == 0.0)
+    assert np.all(sc[:, :-1] <= sc[:, 1:]) and st.queries_fallback <= 4, st.queries_fallback
+    i2, s2 = B.batch_knn_multi(qs[:16], vb, k, engine=innr.KNN_EXACT)
+    assert np.array_equal(idx[:16], i2) and bits_equal(sc[:16], s2)
+    print(f"C2 l2: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")

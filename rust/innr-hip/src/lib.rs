@@ -1,6 +1,7 @@
-//! innr-hip: innr's `batch` API (src/batch.rs) on one MI355X through `include/innr_hip.h`.
+//! innr-hip: innr's `batch`, `scalar::batch_knn_u8`, `maxsim` and `distance` APIs on one MI355X through
+//! `include/innr_hip.h`.
 //!
-//! Same public signatures as `innr::batch`; a reference panic stays a panic (the C ABI returns
+//! Same public signatures as the reference modules; a reference panic stays a panic (the C ABI returns
 //! `INNR_E_DIM_MISMATCH`, this shim re-raises the `assert_eq!` the reference would have hit).
 //! UNCOMPILED in this round (no Rust toolchain in the build image) -- see INTEGRATION.md.
 #![allow(clippy::missing_safety_doc)]
@@ -11,6 +12,8 @@ pub mod ffi {
     pub struct InnrCtx { _p: [u8; 0] }
     #[repr(C)]
     pub struct InnrBatch { _p: [u8; 0] }
+    #[repr(C)]
+    pub struct InnrDocs { _p: [u8; 0] }
     #[repr(C)]
     #[derive(Default, Clone, Copy, Debug)]
     pub struct InnrKnnStats {
@@ -41,6 +44,34 @@ pub mod ffi {
         pub fn innr_batch_norms(b: *mut InnrBatch, out: *mut f32) -> c_int;
         pub fn innr_batch_knn(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int,
                               out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        // L2 variants (batch.rs:320-365, 572-659, 820-882)
+        pub fn innr_batch_dimension_variance(b: *mut InnrBatch, out: *mut f32) -> c_int;
+        pub fn innr_batch_knn_filtered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize, mask: *const u8,
+                                       out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_knn_reordered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize,
+                                        out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_l2_squared_pruning(b: *mut InnrBatch, q: *const f32, d: usize, threshold: f32,
+                                             out_idx: *mut u64, out_dist: *mut f32, cap: usize, out_n: *mut usize) -> c_int;
+        // scalar.rs
+        pub fn innr_batch_upload_u8(ctx: *mut InnrCtx, codes: *const u8, n: usize, d: usize, alpha: f32, offset: f32,
+                                    out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_batch_knn_u8(b: *mut InnrBatch, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int,
+                                 out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_quantize_u8(values: *const f32, n: usize, alpha: f32, offset: f32, out: *mut u8);
+        pub fn innr_mixed_dot_u8_f32(a: *const f32, b: *const u8, n: usize) -> f32;
+        // maxsim.rs
+        pub fn innr_maxsim_pair(q: *const f32, nq: usize, d: *const f32, nd: usize, dim: usize, cosine: c_int, out: *mut f32) -> c_int;
+        pub fn innr_maxsim_upload(ctx: *mut InnrCtx, tokens: *const f32, doc_len: *const u32, docs: usize, t: usize, dim: usize,
+                                  out: *mut *mut InnrDocs) -> c_int;
+        pub fn innr_docs_free(d: *mut InnrDocs);
+        pub fn innr_maxsim_scores(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, out: *mut f32) -> c_int;
+        pub fn innr_maxsim_topk(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int,
+                                out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        // distance.rs / dense.rs portable pairwise functions (host)
+        pub fn innr_dot_f32(a: *const f32, b: *const f32, n: usize) -> f32;
+        pub fn innr_cosine_f32(a: *const f32, b: *const f32, n: usize) -> f32;
+        pub fn innr_l2sq_f32(a: *const f32, b: *const f32, n: usize) -> f32;
+        pub fn innr_l1_f32(a: *const f32, b: *const f32, n: usize) -> f32;
     }
 }
 
@@ -192,4 +223,178 @@ pub mod batch {
     #[must_use] pub fn batch_knn(query: &[f32], batch: &VerticalBatch, k: usize) -> BatchKnnResult { knn1(ffi::INNR_METRIC_L2SQ, query, batch, k) }
     #[must_use] pub fn batch_knn_dot(query: &[f32], batch: &VerticalBatch, k: usize) -> BatchKnnResult { knn1(ffi::INNR_METRIC_DOT, query, batch, k) }
     #[must_use] pub fn batch_knn_cosine(query: &[f32], batch: &VerticalBatch, k: usize) -> BatchKnnResult { knn1(ffi::INNR_METRIC_COSINE, query, batch, k) }
+
+    // ---- L2 variants ------------------------------------------------------------------------------------
+    fn collect(idx: Vec<u64>, sc: Vec<f32>, n: usize) -> BatchKnnResult {
+        BatchKnnResult { indices: idx[..n].iter().map(|&i| i as usize).collect(), scores: sc[..n].to_vec() }
+    }
+
+    /// batch.rs:572-592
+    #[must_use] pub fn batch_dimension_variance(batch: &VerticalBatch) -> Vec<f32> {
+        let mut v = vec![0f32; batch.dimension];
+        check(unsafe { ffi::innr_batch_dimension_variance(batch.handle(), v.as_mut_ptr()) });
+        v
+    }
+
+    /// batch.rs:820-882 -- the predicate is evaluated for every index up front, exactly like the reference (:839)
+    #[must_use] pub fn batch_knn_filtered<F: Fn(usize) -> bool>(query: &[f32], batch: &VerticalBatch, k: usize, predicate: F) -> BatchKnnResult {
+        assert_eq!(query.len(), batch.dimension);
+        if batch.num_vectors == 0 || k == 0 { return BatchKnnResult { indices: Vec::new(), scores: Vec::new() }; }
+        let mask: Vec<u8> = (0..batch.num_vectors).map(|i| predicate(i) as u8).collect();
+        let kk = k.min(batch.num_vectors);
+        let (mut idx, mut sc, mut n) = (vec![0u64; kk], vec![0f32; kk], 0usize);
+        check(unsafe { ffi::innr_batch_knn_filtered(batch.handle(), query.as_ptr(), query.len(), k, mask.as_ptr(),
+                                                    idx.as_mut_ptr(), sc.as_mut_ptr(), &mut n) });
+        collect(idx, sc, n)
+    }
+
+    /// batch.rs:621-659
+    #[must_use] pub fn batch_knn_reordered(query: &[f32], batch: &VerticalBatch, k: usize) -> BatchKnnResult {
+        assert_eq!(query.len(), batch.dimension);
+        if batch.num_vectors == 0 || k == 0 { return BatchKnnResult { indices: Vec::new(), scores: Vec::new() }; }
+        let kk = k.min(batch.num_vectors);
+        let (mut idx, mut sc, mut n) = (vec![0u64; kk], vec![0f32; kk], 0usize);
+        check(unsafe { ffi::innr_batch_knn_reordered(batch.handle(), query.as_ptr(), query.len(), k, idx.as_mut_ptr(), sc.as_mut_ptr(), &mut n) });
+        collect(idx, sc, n)
+    }
+
+    /// batch.rs:320-365: (index, squared distance) of every vector not farther than `threshold`, in index order
+    #[must_use] pub fn batch_l2_squared_pruning(query: &[f32], batch: &VerticalBatch, threshold: f32) -> Vec<(usize, f32)> {
+        assert_eq!(query.len(), batch.dimension);
+        let cap = batch.num_vectors;
+        let (mut idx, mut d, mut n) = (vec![0u64; cap.max(1)], vec![0f32; cap.max(1)], 0usize);
+        check(unsafe { ffi::innr_batch_l2_squared_pruning(batch.handle(), query.as_ptr(), query.len(), threshold,
+                                                          idx.as_mut_ptr(), d.as_mut_ptr(), cap, &mut n) });
+        (0..n.min(cap)).map(|i| (idx[i] as usize, d[i])).collect()
+    }
+}
+
+/// `innr::scalar` (scalar.rs): u8 scalar quantisation with asymmetric (f32 query x u8 code) scoring.
+pub mod scalar {
+    use super::*;
+
+    /// scalar.rs:44-60
+    #[derive(Clone, Copy, Debug, PartialEq)]
+    pub struct QuantizationParams { pub alpha: f32, pub offset: f32 }
+    impl QuantizationParams {
+        pub fn from_range(min: f32, max: f32) -> Self {
+            let alpha = max - min;
+            Self { alpha: if alpha > 0.0 { alpha } else { 1.0 }, offset: min }
+        }
+    }
+
+    /// scalar.rs:171-208
+    #[derive(Clone, Debug, PartialEq)]
+    pub struct QuantizedU8 { pub data: Vec<u8>, pub dimension: usize }
+
+    /// scalar.rs:212-225 (host: one-time ingest)
+    #[must_use] pub fn quantize_u8(values: &[f32], params: &QuantizationParams) -> QuantizedU8 {
+        let mut data = vec![0u8; values.len()];
+        unsafe { ffi::innr_quantize_u8(values.as_ptr(), values.len(), params.alpha, params.offset, data.as_mut_ptr()) };
+        QuantizedU8 { data, dimension: values.len() }
+    }
+
+    /// scalar.rs:314-358, portable order (host: per pair)
+    #[must_use] pub fn mixed_dot_u8_f32(a: &[f32], b: &[u8]) -> f32 {
+        assert_eq!(a.len(), b.len(), "dimension mismatch");
+        unsafe { ffi::innr_mixed_dot_u8_f32(a.as_ptr(), b.as_ptr(), a.len()) }
+    }
+
+    /// A corpus of codes resident on the GPU (the reference passes `&[QuantizedU8]`; upload once, search many times).
+    pub struct QuantizedCorpus { h: *mut ffi::InnrBatch, n: usize, dim: usize }
+    unsafe impl Send for QuantizedCorpus {}
+    unsafe impl Sync for QuantizedCorpus {}
+    impl Drop for QuantizedCorpus { fn drop(&mut self) { unsafe { ffi::innr_batch_free(self.h) } } }
+    impl QuantizedCorpus {
+        pub fn new(corpus: &[QuantizedU8], params: &QuantizationParams) -> Self {
+            let dim = corpus.first().map_or(0, |c| c.dimension);
+            let mut flat = Vec::with_capacity(corpus.len() * dim);
+            for c in corpus { assert_eq!(c.data.len(), dim, "dimension mismatch"); flat.extend_from_slice(&c.data); }
+            let mut h = std::ptr::null_mut();
+            check(unsafe { ffi::innr_batch_upload_u8(ctx(), flat.as_ptr(), corpus.len(), dim, params.alpha, params.offset, &mut h) });
+            Self { h, n: corpus.len(), dim }
+        }
+        /// scalar.rs:370-393 for one query: `(index, score)` best first
+        #[must_use] pub fn knn(&self, query: &[f32], k: usize) -> Vec<(usize, f32)> {
+            if self.n == 0 || k == 0 { return Vec::new(); }
+            let kk = k.min(self.n);
+            let (mut idx, mut sc, mut n) = (vec![0u64; kk], vec![0f32; kk], 0usize);
+            check(unsafe { ffi::innr_batch_knn_u8(self.h, query.as_ptr(), 1, query.len(), k, ffi::INNR_KNN_AUTO,
+                                                  idx.as_mut_ptr(), sc.as_mut_ptr(), &mut n, std::ptr::null_mut()) });
+            (0..n).map(|i| (idx[i] as usize, sc[i])).collect()
+        }
+        pub fn len(&self) -> usize { self.n }
+        pub fn is_empty(&self) -> bool { self.n == 0 }
+        pub fn dimension(&self) -> usize { self.dim }
+    }
+
+    /// scalar.rs:370-393, reference signature (uploads the corpus for this one call)
+    #[must_use] pub fn batch_knn_u8(query: &[f32], corpus: &[QuantizedU8], params: &QuantizationParams, k: usize) -> Vec<(usize, f32)> {
+        if corpus.is_empty() || k == 0 { return Vec::new(); }
+        QuantizedCorpus::new(corpus, params).knn(query, k)
+    }
+}
+
+/// `innr::maxsim` (maxsim.rs:96-194): one pair on the host, a whole corpus on the GPU.
+pub mod maxsim {
+    use super::*;
+
+    fn pair(query_tokens: &[&[f32]], doc_tokens: &[&[f32]], cosine: i32) -> f32 {
+        if query_tokens.is_empty() || doc_tokens.is_empty() { return 0.0; } // maxsim.rs:97-99
+        let dim = query_tokens[0].len();
+        assert!(doc_tokens.iter().all(|t| t.len() == dim), "dimension mismatch (doc)"); // maxsim.rs:103-110
+        assert!(query_tokens.iter().all(|t| t.len() == dim), "dimension mismatch (query)");
+        let q: Vec<f32> = query_tokens.iter().flat_map(|t| t.iter().copied()).collect();
+        let d: Vec<f32> = doc_tokens.iter().flat_map(|t| t.iter().copied()).collect();
+        let mut out = 0f32;
+        check(unsafe { ffi::innr_maxsim_pair(q.as_ptr(), query_tokens.len(), d.as_ptr(), doc_tokens.len(), dim, cosine, &mut out) });
+        out
+    }
+    #[must_use] pub fn maxsim(query_tokens: &[&[f32]], doc_tokens: &[&[f32]]) -> f32 { pair(query_tokens, doc_tokens, 0) }
+    #[must_use] pub fn maxsim_cosine(query_tokens: &[&[f32]], doc_tokens: &[&[f32]]) -> f32 { pair(query_tokens, doc_tokens, 1) }
+
+    /// Token embeddings of many documents, resident on the GPU: replaces the caller's loop + sort
+    /// (examples/maxsim_colbert.rs:171-187) by one call.
+    pub struct DocumentCorpus { h: *mut ffi::InnrDocs, dim: usize }
+    unsafe impl Send for DocumentCorpus {}
+    unsafe impl Sync for DocumentCorpus {}
+    impl Drop for DocumentCorpus { fn drop(&mut self) { unsafe { ffi::innr_docs_free(self.h) } } }
+    impl DocumentCorpus {
+        /// `tokens`: `[docs][max_tokens][dim]` flattened, `doc_len[i]` valid tokens of document i
+        pub fn new(tokens: &[f32], doc_len: Option<&[u32]>, docs: usize, max_tokens: usize, dim: usize) -> Self {
+            assert_eq!(tokens.len(), docs * max_tokens * dim);
+            let mut h = std::ptr::null_mut();
+            let lp = doc_len.map_or(std::ptr::null(), |l| l.as_ptr());
+            check(unsafe { ffi::innr_maxsim_upload(ctx(), tokens.as_ptr(), lp, docs, max_tokens, dim, &mut h) });
+            Self { h, dim }
+        }
+        /// `(document, maxsim score)` of the k best documents, best first; scores identical to `maxsim()` per document
+        #[must_use] pub fn topk(&self, query_tokens: &[&[f32]], k: usize, cosine: bool) -> Vec<(usize, f32)> {
+            let q: Vec<f32> = query_tokens.iter().flat_map(|t| t.iter().copied()).collect();
+            let dim = query_tokens.first().map_or(self.dim, |t| t.len());
+            let (mut idx, mut sc, mut n) = (vec![0u64; k.max(1)], vec![0f32; k.max(1)], 0usize);
+            check(unsafe { ffi::innr_maxsim_topk(self.h, cosine as i32, q.as_ptr(), query_tokens.len(), dim, k, ffi::INNR_KNN_AUTO,
+                                                 idx.as_mut_ptr(), sc.as_mut_ptr(), &mut n, std::ptr::null_mut()) });
+            (0..n).map(|i| (idx[i] as usize, sc[i])).collect()
+        }
+    }
+}
+
+/// `innr::distance` (distance.rs:66-114): per-pair metrics for graph indexes; host functions in the portable order.
+pub mod distance {
+    use super::ffi;
+
+    pub trait Distance<T> { fn eval(&self, a: &[T], b: &[T]) -> f32; }
+    fn pair(f: unsafe extern "C" fn(*const f32, *const f32, usize) -> f32, a: &[f32], b: &[f32]) -> f32 {
+        assert_eq!(a.len(), b.len());
+        unsafe { f(a.as_ptr(), b.as_ptr(), a.len()) }
+    }
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistCosine;
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistDot;
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistL2;
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistL1;
+    impl Distance<f32> for DistCosine { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { 1.0 - pair(ffi::innr_cosine_f32, a, b) } } // distance.rs:73-80
+    impl Distance<f32> for DistDot { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { -pair(ffi::innr_dot_f32, a, b) } }            // :85-92
+    impl Distance<f32> for DistL2 { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { pair(ffi::innr_l2sq_f32, a, b).sqrt() } }      // :96-103
+    impl Distance<f32> for DistL1 { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { pair(ffi::innr_l1_f32, a, b) } }                // :107-114
 }

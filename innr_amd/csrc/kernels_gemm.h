@@ -82,7 +82,11 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
 //                    least) the DMA pieces of step s+2 issued during s, so the pieces of step s+1 (issued during
 //                    s-1) are in LDS; epilogue traffic issued later only makes the wait stricter.
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifdef INNR_GEMM_PROBE_NOWAIT  // tools/gemm_probe.hip: issue the DMA but never wait for it
+__device__ __forceinline__ void wait_but_last() {}
+#else
 __device__ __forceinline__ void wait_but_last() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+#endif
 
 __device__ __forceinline__ void wait_but_last5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 __device__ __forceinline__ void wait_but_last4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
@@ -104,7 +108,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
-    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
+    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump,
+    uint32_t stagger) {
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
@@ -129,6 +134,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const uint32_t nk = Dpad / kBK;
     const uint32_t total = (t1 - t0) * nk;
 
+    // The two blocks that share a CU run the same K-step loop at the same rate (they alternate on the MFMA pipe), so
+    // left alone they reach their barriers and LDS-latency bubbles together and nothing covers them. The second half
+    // of the grid (the blocks dispatched into the second slot of each CU) starts `stagger` x 64 cycles late.
+    if (blockIdx.x >= gridDim.x / 2)
+        for (uint32_t i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
     s.cnt[threadIdx.x] = 0;  // kBQ == kGemmThreads
     s.thr[threadIdx.x] = 0;
     uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
@@ -167,7 +177,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     // pointer strides in floats (pa is a float* also for u8: byte strides are multiples of 4)
     const size_t a_step = U8 ? (size_t)kBK * ldN / 4 : (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
     // subtract at a tile change: back to row 0, next tile
+#ifdef INNR_GEMM_PROBE_L2HOT  // tools/gemm_probe.hip: every block re-reads corpus tile 0 (L2-resident operands)
+    const size_t a_wrap = (size_t)(Dpad - kBK) * ldN;
+    pa[0] -= (size_t)t0 * kBC;
+    pa[1] -= (size_t)t0 * kBC;
+#else
     const size_t a_wrap = U8 ? ((size_t)(Dpad - kBK) * ldN - kBC) / 4 : (size_t)(Dpad - kBK) * ldN - kBC;
+#endif
     const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad;
     uint32_t pks = 0;  // K-step index the pointers refer to
     auto advance = [&]() {
@@ -249,17 +265,24 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                     av[h].w = (float)(c4 >> 24);
                 }
             }
+#ifndef INNR_GEMM_PROBE_NODMA  // tools/gemm_probe.hip
             if (has_next) {
                 if (grp == 0) {
+#ifndef INNR_GEMM_PROBE_NODMA_A
                     issue_a(da);
-                } else if (grp == 1) {
+#endif
+                }
+#ifndef INNR_GEMM_PROBE_NODMA_B
+                else if (grp == 1) {
                     glds16(pq[0], lq[0] + dq);
                     glds16(pq[1], lq[1] + dq);
                 } else if (grp == 2) {
                     glds16(pq[2], lq[2] + dq);
                     glds16(pq[3], lq[3] + dq);
                 }
+#endif
             }
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float a[4] = {av[h].x, av[h].y, av[h].z, av[h].w};
@@ -274,7 +297,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         }
         if (has_next) advance();
 
+#ifdef INNR_GEMM_PROBE_NOEPI  // tools/gemm_probe.hip: K-loop only (accumulators keep running, results meaningless)
+        if (false) {
+#else
         if (ks + 1 == nk) {
+#endif
             // ---------------- epilogue for corpus tile `tile` ----------------
             const size_t tb = (size_t)tile * kBC;
             const int half = lane >> 5, C = lane & 31;
@@ -406,14 +433,30 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             ++ks;
         }
         // This wave's pieces of K-step s+1 (issued one step ago) are in LDS; the pieces of s+2 stay in flight.
+#ifdef INNR_GEMM_PROBE_NOWAIT
+        if (false) wait_all();
+#else
         if (!has_next) wait_all();
+#endif
         else if (!U8) wait_but_last();     // 6 pieces per wave per step
         else if (a_issuer) wait_but_last5();  // u8: waves 0-1 issue 1 + 4 pieces,
         else wait_but_last4();                //     waves 2-3 issue 4
+#ifndef INNR_GEMM_PROBE_NOBAR  // tools/gemm_probe.hip
         __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step
+#endif
         st = (st == 2) ? 0u : st + 1;
     }
 
+#ifdef INNR_GEMM_PROBE_NOEPI  // keep the accumulators alive
+    if (KP == 0xFFFFFFFFu) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) reinterpret_cast<float*>(lists)[threadIdx.x + 256 * (g + 16 * (ct + 2 * rt))] = acc[rt][ct][g];
+    }
+#endif
     if (MODE == 0) {
         // leave <= KP entries per list and publish the counts (every query of the tile, padded ones too)
         const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -1,0 +1,41 @@
+// gemm_probe.hip -- where does gemm_filter_kernel's time go at C2 (10M x 768, 1024 queries)? Build variants:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off [-DINNR_GEMM_PROBE_NOEPI] [-DINNR_GEMM_PROBE_NODMA]
+//         [-DINNR_GEMM_PROBE_NOBAR] -o gemm_probe tools/gemm_probe.hip && ./gemm_probe
+// (NOEPI: K-loop only; NODMA: no LDS-DMA inside the loop; NOBAR: no per-step barrier. Results are meaningless in
+//  the probe variants -- only the time is read.)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../innr_amd/csrc/common.h"
+#include "../innr_amd/csrc/topk_dev.h"
+#include "../innr_amd/csrc/kernels_prep.h"
+#include "../innr_amd/csrc/kernels_gemm.h"
+using namespace innr;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main(int argc, char** argv) {
+    const size_t N = argc > 1 ? atol(argv[1]) : 10000000, D = 768, Q = 1024, ldN = (N + 255) / 256 * 256, Qpad = Q;
+    const uint32_t KP = 32, cap = 384, nqt = Q / kBQ, ns = 128, ntiles = ldN / kBC, tps = (ntiles + ns - 1) / ns;
+    float *V, *Qt;
+    uint64_t* lists; uint32_t *counts, *gs, *err;
+    CK(hipMalloc(&V, ldN * D * 4)); CK(hipMalloc(&Qt, D * Qpad * 4));
+    CK(hipMalloc(&lists, (size_t)ns * Qpad * cap * 8)); CK(hipMalloc(&counts, (size_t)ns * Qpad * 4));
+    CK(hipMalloc(&gs, (Qpad * KP + Qpad) * 4)); CK(hipMalloc(&err, 4096));
+    generate_pdx_kernel<1><<<dim3((unsigned)((ldN / 4 + 255) / 256), (unsigned)D), 256>>>(V, ldN, (uint32_t)N, (uint32_t)D, 0, 0);
+    generate_pdx_kernel<1><<<dim3((unsigned)((Qpad / 4 + 255) / 256), (unsigned)D), 256>>>(Qt, Qpad, (uint32_t)Q, (uint32_t)D, 0xBE7C, 0);
+    CK(hipMemset(err, 0, 4096));
+    CK(hipDeviceSynchronize());
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9;
+    for (int it = 0; it < 4; ++it) {
+        CK(hipMemset(gs, 0, (Qpad * KP + Qpad) * 4));
+        hipEventRecord(a);
+        gemm_filter_kernel<kGemmDot, 6, 0><<<nqt * ns, kGemmThreads>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
+                                                                       1.0f, lists, counts, KP, err, gs, gs + Qpad * KP, nullptr, 0, 0);
+        hipEventRecord(b); CK(hipEventSynchronize(b));
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    printf("gemm_filter_kernel %zux%zu x %zu queries: %.2f ms -> %.1f TFLOP/s (%.1f %% of 157.3)\n", N, D, Q, best,
+           2.0 * N * D * Q / best / 1e9, 2.0 * N * D * Q / best / 1e9 / 1.573);
+    return 0;
+}

@@ -41,12 +41,11 @@ constexpr int kGemmBurst = kBC;  // most appends one tile can make to one query'
 constexpr int kStages = 3;  // LDS ring: the DMA for K-step s+2 is issued during step s (two steps of cover)
 
 struct alignas(16) GemmLds {
-    alignas(16) float A[kStages][kBK][kBC];  // 3 x 8 KiB
-    alignas(16) float B[kStages][kBK][kBQ];  // 3 x 16 KiB
+    alignas(16) float A[kStages][kBK][kBC];  // 3 x 8 KiB: the corpus tile, shared by the block's four waves
     uint32_t cnt[kBQ];
     uint32_t thr[kBQ];
 };
-constexpr uint32_t kStageBytesA = kBK * kBC * 4, kStageBytesB = kBK * kBQ * 4;
+constexpr uint32_t kStageBytesA = kBK * kBC * 4;
 
 // One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS [M0 .. M0 + 1 KiB), linear.
 // Written as inline asm on purpose: for the builtin, hipcc (ROCm 7.2) treats every later ds_read as aliasing
@@ -72,24 +71,36 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
     return __builtin_amdgcn_readfirstlane(a);
 }
 
-// Staging of one K-step (16 dimension rows of the corpus tile and of the query tile): each wave issues 6 LDS-DMA
-// instructions of 1 KiB -- 2 for the corpus (2 rows of 512 B each) and 4 for the queries (1 row of 1 KiB each).
-// LDS destination = wave-uniform base + lane*16 (linear), source address per lane.
+// Operand feed of one K-step (16 dimensions):
+//   corpus tile (16 x 128 floats, shared by the four waves): 2 LDS-DMA instructions of 1 KiB per wave into the ring,
+//     LDS destination = wave-uniform base + lane*16 (linear), source address per lane; issued two steps ahead;
+//   queries: every wave multiplies its OWN 64 queries, so their fragments never need to be shared: each lane loads
+//     its B operands (2 floats per k-pair: queries 64w + 2(l&31) + {0,1}, dimension 2kp + (l>>5)) straight from the
+//     K-major query matrix (L2-resident) into the registers the previous step just freed, one step ahead.
+//     (Staging them through LDS as well cost 16 KiB of DMA writes + 16 KiB of ds_reads per block per step:
+//      tools/gemm_probe.hip attributed 12 % of the kernel time to exactly that traffic.)
 //
-// vmcnt counts every VMEM op of the wave in issue order (DMA, epilogue loads/stores alike).
-//   wait_all():      everything this wave issued has completed.
-//   wait_but_last(): all but the 6 youngest ops have completed. At the end of K-step s the 6 youngest are (at
-//                    least) the DMA pieces of step s+2 issued during s, so the pieces of step s+1 (issued during
-//                    s-1) are in LDS; epilogue traffic issued later only makes the wait stricter.
+// vmcnt counts every VMEM op of the wave in issue order (DMA, query loads, epilogue loads/stores alike). Per step a
+// wave issues, in this order: corpus DMA of step s+2 (2 ops; u8: 1 or 0), then 8 query loads for step s+1. The
+// compiler inserts the waits for the query loads (it does not see the inline-asm DMA, so its counts are only ever
+// stricter than needed, and never so strict as to wait for the youngest DMA); the end-of-step wait below leaves
+// exactly those youngest ops in flight: the corpus pieces of step s+1 (issued during s-1) are then in LDS.
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #ifdef INNR_GEMM_PROBE_NOWAIT  // tools/gemm_probe.hip: issue the DMA but never wait for it
-__device__ __forceinline__ void wait_but_last() {}
+template <int N> __device__ __forceinline__ void wait_but_youngest() {}
 #else
-__device__ __forceinline__ void wait_but_last() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <int N> __device__ __forceinline__ void wait_but_youngest() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
-__device__ __forceinline__ void wait_but_last5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-__device__ __forceinline__ void wait_but_last4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+// Query-operand load (8 B per lane) and its use-side wait, both inline asm: left to the compiler, the waits for
+// these loop-carried loads come out as vmcnt(1..3) -- it cannot see the DMA ops in between and resolves the loop
+// back-edge conservatively -- which exposes an L2 round trip in every group. dst is valid only after use_after<N>.
+__device__ __forceinline__ void gload2(float2& dst, const float* p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void use_after(float2& a, float2& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
 
 enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 
@@ -151,13 +162,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
 
-    // Per-lane source pointers of this wave's 6 DMA pieces (2 corpus, 4 query), advanced incrementally so the
-    // K-loop carries no 64-bit multiplies; wave-uniform LDS destinations of both stages, computed once.
+    // Per-lane source pointers of this wave's 2 corpus DMA pieces and of its query operands, advanced incrementally
+    // so the K-loop carries no 64-bit multiplies; wave-uniform LDS destinations computed once.
     const float* pa[2];
-    const float* pq[4];
-    uint32_t la[2], lq[4];  // stage-0 destinations; stage k adds k * kStageBytes{A,B}
-    // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each), issued by waves 0 and 1 (pa[0] only)
-    const bool a_issuer = !U8 || __builtin_amdgcn_readfirstlane(w) < 2;
+    uint32_t la[2];  // stage-0 destinations; stage k adds k * kStageBytesA
+    // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each): piece (w & 1) from every wave (pa[0] only)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (U8) {
@@ -169,11 +178,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        pq[j] = Qt + (size_t)(4 * w + j) * Qpad + q0 + (size_t)lane * 4;
-        lq[j] = lds_addr_uniform(&s.B[0][4 * w + j][0]);
-    }
+    // B operands: k-pair kp of the K-step the pointer refers to sits at pb + kp * 2 * Qpad
+    const float* pb = Qt + (size_t)(lane >> 5) * Qpad + q0 + 64 * w + 2 * (lane & 31);
+    const size_t b_kp = 2 * Qpad;
     // pointer strides in floats (pa is a float* also for u8: byte strides are multiples of 4)
     const size_t a_step = U8 ? (size_t)kBK * ldN / 4 : (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
     // subtract at a tile change: back to row 0, next tile
@@ -185,55 +192,63 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const size_t a_wrap = U8 ? ((size_t)(Dpad - kBK) * ldN - kBC) / 4 : (size_t)(Dpad - kBK) * ldN - kBC;
 #endif
     const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad;
-    uint32_t pks = 0;  // K-step index the pointers refer to
+    uint32_t pks = 0, bks = 0;  // K-step index (within a tile) that pa / pb refer to
     auto advance = [&]() {
         if (++pks == nk) {
             pks = 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) pa[j] -= a_wrap;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pq[j] -= q_wrap;
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) pa[j] += a_step;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pq[j] += q_step;
+        }
+    };
+    auto advance_b = [&]() {
+        if (++bks == nk) {
+            bks = 0;
+            pb -= q_wrap;
+        } else {
+            pb += q_step;
         }
     };
     auto issue_a = [&](uint32_t stage_off) {
         if (U8) {
-            if (a_issuer) glds16(pa[0], la[0] + stage_off);
+            glds16(pa[0], la[0] + stage_off);  // waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
         } else {
             glds16(pa[0], la[0] + stage_off);
             glds16(pa[1], la[1] + stage_off);
         }
     };
-    // prologue: K-steps 0 and 1 into stages 0 and 1
+    // prologue: corpus K-steps 0 and 1 into stages 0 and 1, query operands of K-step 0 into registers
+    // (pa always refers to the last K-step issued: advance, then issue -- so a pointer never leaves the slice)
+    if (total) issue_a(0);
+    if (total > 1) {
+        advance();
+        issue_a(kStageBytesA);
+    }
+    float2 breg[kBK / 2];  // this wave's B operands of the current K-step, refilled pair by pair for the next one
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if ((uint32_t)p < total) {
-            issue_a(p * kStageBytesA);
+    for (int kp = 0; kp < kBK / 2; ++kp) breg[kp] = make_float2(0.f, 0.f);
+    if (total) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(pq[j], lq[j] + p * kStageBytesB);
-            advance();
-        }
+        for (int kp = 0; kp < kBK / 2; ++kp) gload2(breg[kp], pb + kp * b_kp);
+        advance_b();  // pb wraps inside the query matrix at every tile change: always a mapped address
     }
     wait_all();
+#pragma unroll
+    for (int kp = 0; kp < kBK / 2; kp += 2) use_after<0>(breg[kp], breg[kp + 1]);
     __syncthreads();  // stages 0 and 1 visible to every wave
 
     uint32_t tile = t0, ks = 0;
     uint32_t st = 0;  // stage holding the current K-step; the DMA of step+2 goes to stage (st + 2) % 3
     for (uint32_t step = 0; step < total; ++step) {
-        const bool has_next = step + 2 < total;  // wave-uniform: is there a K-step to prefetch?
+        const bool has_next = step + 2 < total;   // wave-uniform: is there a corpus K-step to prefetch?
         const uint32_t dst = (st == 0) ? 2u : st - 1;
-        const uint32_t da = dst * kStageBytesA, dq = dst * kStageBytesB;
-        // 4 groups of 2 k-pairs: fragment reads, then (groups 0-2) two LDS-DMA pieces of K-step s+2 into the ring
-        // stage that step s-1 released -- issued while the fragment reads are in flight -- then 16 MFMAs.
-        // Spreading the DMA issue keeps every non-MFMA stretch short enough to hide behind queued MFMAs.
-        // Fragments are software-pipelined one group ahead (two register sets): group g+1's LDS reads are issued
-        // before group g's MFMAs, so only the first group of a step (right after the barrier) exposes LDS latency.
+        const uint32_t da = dst * kStageBytesA;
+        // 4 groups of 2 k-pairs: A-fragment reads (software-pipelined one group ahead: two register sets, so only the
+        // first group of a step, right after the barrier, exposes LDS latency), 16 MFMAs, then the two B registers the
+        // group just consumed are reloaded for the next K-step.
         float4 avs[2][2];
-        float2 bvs[2][2];
         auto read_frags = [&](int grp, int set) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -245,16 +260,26 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 } else {
                     avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
                 }
-                bvs[set][h] = *reinterpret_cast<const float2*>(&s.B[st][2 * kp + (lane >> 5)][64 * w + 2 * (lane & 31)]);
             }
         };
         read_frags(0, 0);
+        // the corpus DMA of step s+2 goes out first: every later wait of this step then sees it among the younger ops
+#ifndef INNR_GEMM_PROBE_NODMA_A  // tools/gemm_probe.hip
+        if (has_next) advance();
+        issue_a(da);
+#endif
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int cur = grp & 1;
             if (grp < 3) read_frags(grp + 1, cur ^ 1);
             float4 av[2] = {avs[cur][0], avs[cur][1]};
-            const float2(&bv)[2] = bvs[cur];
+            // Every step issues the same VMEM sequence (corpus DMA, then 4 x 2 query loads; past the end of the slice
+            // they re-fetch the last step / wrap, into a stage and registers nobody reads), so the ops younger than
+            // this group's operands (loaded one step ago, after the same group) are always 6 query loads + the corpus
+            // DMA (f32: 2 ops, u8: 1). One unconditional wait: a branch here made hipcc copy the registers BEFORE it.
+            if (U8) use_after<7>(breg[2 * grp], breg[2 * grp + 1]);
+            else use_after<8>(breg[2 * grp], breg[2 * grp + 1]);
+            const float2 bv[2] = {breg[2 * grp], breg[2 * grp + 1]};
             if (U8) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -265,24 +290,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                     av[h].w = (float)(c4 >> 24);
                 }
             }
-#ifndef INNR_GEMM_PROBE_NODMA  // tools/gemm_probe.hip
-            if (has_next) {
-                if (grp == 0) {
-#ifndef INNR_GEMM_PROBE_NODMA_A
-                    issue_a(da);
-#endif
-                }
-#ifndef INNR_GEMM_PROBE_NODMA_B
-                else if (grp == 1) {
-                    glds16(pq[0], lq[0] + dq);
-                    glds16(pq[1], lq[1] + dq);
-                } else if (grp == 2) {
-                    glds16(pq[2], lq[2] + dq);
-                    glds16(pq[3], lq[3] + dq);
-                }
-#endif
-            }
-#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float a[4] = {av[h].x, av[h].y, av[h].z, av[h].w};
@@ -293,9 +300,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                     for (int ct = 0; ct < 2; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bb[ct], acc[rt][ct], 0, 0, 0);
             }
+#ifndef INNR_GEMM_PROBE_NODMA_B  // tools/gemm_probe.hip
+            gload2(breg[2 * grp], pb + (2 * grp) * b_kp);
+            gload2(breg[2 * grp + 1], pb + (2 * grp + 1) * b_kp);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (has_next) advance();
+        advance_b();
 
 #ifdef INNR_GEMM_PROBE_NOEPI  // tools/gemm_probe.hip: K-loop only (accumulators keep running, results meaningless)
         if (false) {
@@ -432,20 +443,17 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         } else {
             ++ks;
         }
-        // This wave's pieces of K-step s+1 (issued one step ago) are in LDS; the pieces of s+2 stay in flight.
-#ifdef INNR_GEMM_PROBE_NOWAIT
-        if (false) wait_all();
-#else
-        if (!has_next) wait_all();
-#endif
-        else if (!U8) wait_but_last();     // 6 pieces per wave per step
-        else if (a_issuer) wait_but_last5();  // u8: waves 0-1 issue 1 + 4 pieces,
-        else wait_but_last4();                //     waves 2-3 issue 4
+        // This wave's corpus pieces of K-step s+1 (issued one step ago) are in LDS; the youngest ops -- the corpus
+        // pieces of s+2 and the 8 query loads of s+1 -- stay in flight.
+        if (U8) wait_but_youngest<9>();
+        else wait_but_youngest<10>();
 #ifndef INNR_GEMM_PROBE_NOBAR  // tools/gemm_probe.hip
         __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step
 #endif
         st = (st == 2) ? 0u : st + 1;
     }
+    wait_all();  // the trailing (unused) DMA and loads must land before this block's LDS and registers are released
+    __syncthreads();
 
 #ifdef INNR_GEMM_PROBE_NOEPI  // keep the accumulators alive
     if (KP == 0xFFFFFFFFu) {

@@ -101,6 +101,13 @@ __device__ __forceinline__ void gload2(float2& dst, const float* p) {
 template <int N> __device__ __forceinline__ void use_after(float2& a, float2& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
+// agent-coherent dword load (sc1: served by L2, where the atomics that update it execute), same contract as gload2
+__device__ __forceinline__ void gload1_agent(uint32_t& dst, const uint32_t* p) {
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void use_after(uint32_t& a, uint32_t& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
 
 enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 
@@ -239,6 +246,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     for (int kp = 0; kp < kBK / 2; kp += 2) use_after<0>(breg[kp], breg[kp + 1]);
     __syncthreads();  // stages 0 and 1 visible to every wave
 
+    uint32_t tg_next[2] = {0u, 0u};  // chip-wide thresholds of this lane's two queries, refreshed once per tile
+    float iq_lane[2] = {1.0f, 1.0f};  // per-query epilogue constant: COS 1/||q||; U8 offset * sum(q); L2 C_j - |q_j|^2
+    if (COS || U8 || L2K) {
+        iq_lane[0] = invq[q0 + 64 * w + 2 * (lane & 31) + 0];
+        iq_lane[1] = invq[q0 + 64 * w + 2 * (lane & 31) + 1];
+    }
     uint32_t tile = t0, ks = 0;
     uint32_t st = 0;  // stage holding the current K-step; the DMA of step+2 goes to stage (st + 2) % 3
     for (uint32_t step = 0; step < total; ++step) {
@@ -335,24 +348,21 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 // Threshold of each of this lane's two queries: the better of the list's own (KP-th best it holds)
                 // and the chip-wide bound gthr[q] (topk_dev.h, global threshold slots).
                 uint32_t thr[2];
+                if (tile != t0) use_after<10>(tg_next[0], tg_next[1]);  // loaded a whole tile ago; wave-uniform branch
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const uint32_t tl = __hip_atomic_load(&s.thr[64 * w + 2 * C + ct], __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    const uint32_t tg = __hip_atomic_load(&gthr[q0 + 64 * w + 2 * C + ct], __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-                    thr[ct] = tl > tg ? tl : tg;
+                    // chip-wide bound as read at the end of the previous tile's epilogue: one tile stale (a stale
+                    // bound is only weaker), but its L2 round trip is no longer on this wave's critical path
+                    thr[ct] = tl > tg_next[ct] ? tl : tg_next[ct];
                 }
                 // Fast reject. For a threshold that is a non-negative float (the normal case once a list has KP
                 // entries), "some value >= thr in total order" == "max over RAW BIT PATTERNS compared as signed
                 // ints >= raw(thr)": non-negative floats (and +NaN, the greatest) order like their bits and every
                 // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
                 int32_t best[2] = {INT32_MIN, INT32_MIN};
-                float iq[2] = {1.0f, 1.0f};
-                if (COS || U8 || L2K) {  // COS: 1/||q||; U8: offset * sum(q); L2: C_j - |q_j|^2
-                    iq[0] = invq[q0 + 64 * w + 2 * C + 0];
-                    iq[1] = invq[q0 + 64 * w + 2 * C + 1];
-                }
+                const float iq[2] = {iq_lane[0], iq_lane[1]};
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {  // 16 consecutive corpus rows: tb + 4*(8*gq + 4*half) + [0,16)
                     const float4* p = reinterpret_cast<const float4*>(invn + tb + 4 * (8 * gq + 4 * half));
@@ -438,6 +448,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
+            if (MODE == 0) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], &gthr[q0 + 64 * w + 2 * (lane & 31) + ct]);
+            }
             ks = 0;
             ++tile;
         } else {

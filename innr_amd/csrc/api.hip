@@ -209,7 +209,7 @@ struct ScanExt {
 template <int QB, int R>
 static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
                                         uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cps,
-                                        const ScanExt& ext) {
+                                        const ScanExt& ext, uint32_t groups) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
@@ -217,20 +217,20 @@ static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* 
     const uint32_t N = (uint32_t)b->N, D = (uint32_t)b->D;
     switch (metric) {
         case INNR_METRIC_DOT:
-            scan_filter_kernel<QB, false, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+            scan_filter_kernel<QB, false, false, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
                 b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         case INNR_METRIC_L2SQ:
             if (ext.mask || ext.order)
-                scan_filter_kernel<QB, true, false, R, true><<<nblocks, kScanThreads, 0, c->stream>>>(
+                scan_filter_kernel<QB, true, false, R, true><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
                     b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err, ext.mask,
                     ext.order);
             else
-                scan_filter_kernel<QB, true, false, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+                scan_filter_kernel<QB, true, false, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
                     b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
             break;
         default:
-            scan_filter_kernel<QB, false, true, R><<<nblocks, kScanThreads, 0, c->stream>>>(
+            scan_filter_kernel<QB, false, true, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
                 b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cps, err);
             break;
     }
@@ -241,11 +241,11 @@ static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* 
 template <int QB>
 static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
                                       uint32_t nblocks, uint32_t qstride, uint32_t KP, uint32_t cap, uint32_t cps,
-                                      const ScanExt& ext) {
+                                      const ScanExt& ext, uint32_t groups = 1) {
     switch (cap) {
-        case 384: return launch_scan_filter_r<QB, 6>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
-        case 768: return launch_scan_filter_r<QB, 12>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
-        default: return launch_scan_filter_r<QB, 20>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext);
+        case 384: return launch_scan_filter_r<QB, 6>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext, groups);
+        case 768: return launch_scan_filter_r<QB, 12>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext, groups);
+        default: return launch_scan_filter_r<QB, 20>(b, metric, dQ, ldq, dQn, nblocks, qstride, KP, cps, ext, groups);
     }
 }
 
@@ -265,29 +265,36 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
     const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
     const uint32_t nblocks = (uint32_t)(nslots / (kScanThreads / 64));
     constexpr uint32_t QBMAX = 8;
-    INNR_TRY(c->lists.ensure(nslots * QBMAX * cap * sizeof(uint64_t)));
-    INNR_TRY(c->counts.ensure(nslots * QBMAX * sizeof(uint32_t)));
-    INNR_TRY(c->sel.ensure(QBMAX * KP * sizeof(uint64_t)));
-    INNR_TRY(c->sel_cnt.ensure(QBMAX * sizeof(uint32_t)));
+    // A corpus that stays in the Infinity Cache (<= 128 MB) is cheap to re-read and too small to fill the chip with
+    // one group of 8 queries: all the 8-query groups go into ONE launch (blockIdx.y), within 256 MB of list space.
+    // Large corpora keep one group per launch (each launch streams HBM once and fills the chip by itself).
+    size_t max_groups = 1;
+    if (b->ldN * b->D * sizeof(float) <= (size_t)128 << 20)
+        max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * QBMAX * cap * sizeof(uint64_t)));
+    max_groups = std::min<size_t>(max_groups, 65535);
     const bool l2 = metric == INNR_METRIC_L2SQ;
     size_t done = 0;
     while (done < nq) {
         const size_t rem = nq - done;
         const uint32_t qb = rem >= 8 ? 8 : (rem >= 4 ? 4 : 1);
+        const uint32_t groups = qb == 8 ? (uint32_t)std::min<size_t>(rem / 8, max_groups) : 1u;
+        const uint32_t nql = qb * groups;  // queries in this launch
+        INNR_TRY(c->lists.ensure(nslots * nql * cap * sizeof(uint64_t)));
+        INNR_TRY(c->counts.ensure(nslots * nql * sizeof(uint32_t)));
         const float* q = dQ + (q0 + done) * ldq;
         const float* qn = dQn ? dQn + q0 + done : nullptr;
         switch (qb) {
-            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
-            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
-            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, qb, KP, cap, cps, ext)); break;
+            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext, groups)); break;
+            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
+            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
         }
-        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, qb, cap, KP, qb));
-        const uint32_t total = qb * (uint32_t)kout;
+        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
+        const uint32_t total = nql * (uint32_t)kout;
         emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
-            c->sel.as<uint64_t>(), KP, qb, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
+            c->sel.as<uint64_t>(), KP, nql, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
             d_out_score + (q0 + done) * kout);
         INNR_HIP_CHECK(hipGetLastError());
-        done += qb;
+        done += nql;
     }
     return INNR_OK;
 }
@@ -835,7 +842,9 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
-    if (engine == INNR_KNN_AUTO) engine = (Q >= 16) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
+    // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
+    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     const float* dQn = nullptr;
@@ -1153,7 +1162,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     float* qnorm = qsum + round_up(Q, kBQ);
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
-    if (engine == INNR_KNN_AUTO) engine = Q >= 16 ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
     uint32_t nfallback = 0, kept = pick_kp(kout, 0);
     float gemm_ms = 0.0f;
     if (engine == INNR_KNN_MFMA) {

@@ -112,10 +112,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
         s_thr[w][lane] = 0;  // pref 0 = no threshold: everything is admitted
     }
     __builtin_amdgcn_wave_barrier();
+    // blockIdx.y = query group: QB consecutive queries each; lists/counts are indexed [slot][query of the launch]
+    // (qstride = queries in the launch). Small corpora put all their query groups into one launch.
+    const uint32_t qoff = blockIdx.y * QB;
+    Qm += (size_t)qoff * ldq;
+    if (COS) qnorm += qoff;
     const size_t nchunks = ldN / kScanChunk;
     size_t ch0 = slot * chunks_per_slot, ch1 = ch0 + chunks_per_slot;
     if (ch1 > nchunks) ch1 = nchunks;
-    uint64_t* my_lists = lists + slot * (size_t)qstride * cap;
+    uint64_t* my_lists = lists + (slot * (size_t)qstride + qoff) * cap;
     for (size_t ch = ch0; ch < ch1; ++ch) {
         const size_t col = ch * kScanChunk + (size_t)lane * 4;
         float acc[QB][4];
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
             uint32_t t;
             c = wave_compact<R>(my_lists + (size_t)j * cap, c, KP, &t);
         }
-        if (lane == 0) counts[slot * qstride + j] = c;
+        if (lane == 0) counts[slot * qstride + qoff + j] = c;
     }
 }
 

@@ -152,7 +152,7 @@ def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
 
 
 def test_knn_auto_engine_selection(B, innr):
-    vb = B.VerticalBatch.generate(3000, 64, 0)
+    vb = B.VerticalBatch.generate(100_000, 64, 0)
     st = innr.KnnStats()
     B.batch_knn_dot_multi(_queries(4, 64, uniform=True), vb, 5, stats=st)
     assert st.engine == innr.KNN_EXACT
@@ -160,6 +160,9 @@ def test_knn_auto_engine_selection(B, innr):
     assert st.engine == innr.KNN_MFMA
     B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
     assert st.engine == innr.KNN_MFMA and st.queries_fallback <= 1
+    small = B.VerticalBatch.generate(3000, 64, 0)  # a few tiles per slice: the exact engine, all query groups in one launch
+    B.batch_knn_dot_multi(_queries(64, 64, uniform=True), small, 5, stats=st)
+    assert st.engine == innr.KNN_EXACT
 
 
 # ------------------------------------------------------------------------------- larger sizes: engine agreement

@@ -147,6 +147,14 @@ void innr_quantize_u8(const float* values, size_t n, float alpha, float offset, 
 /* mixed_dot_u8_f32 for one pair (scalar.rs:314-358, portable loop), host function like the other pairwise ones */
 float innr_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n);
 
+/* corpus ingest on the device: codes of a resident f32 batch, out = quantize_u8 of every value (scalar.rs:212-225);
+ * the new batch inherits the index base. */
+innr_status innr_batch_quantize_u8(innr_batch* f32_batch, float alpha, float offset, innr_batch** out);
+/* QuantizationParams::fit's range (scalar.rs:68-87) of a resident f32 batch: global min / max, NaN ignored;
+ * *out_any = 0 when the batch holds no non-NaN value (the reference then returns alpha 1, offset 0). The order of
+ * the reference's sequential scan decides between -0.0 and +0.0; here -0.0 < +0.0. */
+innr_status innr_batch_minmax(innr_batch* f32_batch, float* out_min, float* out_max, int* out_any);
+
 /* ---- maxsim over a document corpus (src/maxsim.rs:96-194; caller shape examples/maxsim_colbert.rs:159-193) ---- */
 typedef struct innr_docs innr_docs; /* device-resident token embeddings of `docs` documents, T tokens x dim each */
 /* tokens: [docs*T*dim] row-major (document, token, dim); doc_len[docs] = valid tokens per document (<= T) or NULL */
@@ -195,6 +203,16 @@ float innr_l1_f32(const float* a, const float* b, size_t n);     /* dense::l1_di
 /* maxsim / maxsim_cosine of ONE (query, document) pair (maxsim.rs:96-194, portable path :142-152); tokens packed
  * row-major [n][dim]; cosine != 0 selects maxsim_cosine. Empty query or document -> 0.0. */
 innr_status innr_maxsim_pair(const float* q, size_t nq, const float* d, size_t nd, size_t dim, int cosine, float* out);
+
+/* ---- second stage of the two-stage pipeline (scalar.rs:366-368: u8 first pass, exact re-rank) --------------- */
+/* exact scores (reference arithmetic order, like innr_batch_knn's) of caller-given candidates cand[Q][kc] (global
+ * indices inside this batch's range, no duplicates within a query, kc <= 256), best min(k, kc) per query in the
+ * kNN functions' order (dot/cosine: score desc; L2SQ: distance asc; ties: index asc). */
+innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, const uint64_t* cand,
+                              size_t kc, size_t k, uint64_t* out_idx, float* out_score, size_t* out_k);
+innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D,
+                                  const uint64_t* d_cand, size_t kc, size_t k, uint64_t* d_out_idx, float* d_out_score,
+                                  size_t* out_k);
 
 /* ---- multi-GPU merge (range partition + all-gather of per-shard top-k) --------- */
 /* in: G shards x Q queries x kin candidates (device pointers, layout [g][q][kin], global indices);

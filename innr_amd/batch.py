@@ -238,6 +238,32 @@ def knn_multi(metric: int, queries, batch: VerticalBatch, k: int, engine: int = 
     return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
 
 
+def batch_rerank(queries, batch: VerticalBatch, candidates, k: int, metric: int = METRIC_DOT):
+    """Second stage of the two-stage pipeline (scalar.rs:366-368): exact scores of `candidates` [Q, kc] (global indices
+    inside `batch`, no duplicates per query, kc <= 256) in the reference's arithmetic order, best min(k, kc) per query in
+    the kNN functions' order. Returns (indices uint64 [Q, k'], scores float32 [Q, k'])."""
+    q = _f32(queries)
+    if q.ndim == 1:
+        q = q.reshape(1, -1)
+    nq, d = q.shape
+    if d != batch.dimension():
+        raise InnrPanic(f"assertion `left == right` failed\n  left: {d}\n right: {batch.dimension()}")
+    cand = np.ascontiguousarray(candidates, dtype=np.uint64)
+    if cand.ndim == 1:
+        cand = cand.reshape(1, -1)
+    if cand.shape[0] != nq:
+        raise InnrPanic("one candidate row per query")
+    kc = cand.shape[1]
+    kk = max(min(int(k), kc), 1)
+    idx = np.empty((nq, kk), dtype=np.uint64)
+    sc = np.empty((nq, kk), dtype=np.float32)
+    out_k = C.c_size_t(0)
+    check(load().innr_batch_rerank(batch._h, metric, _vp(q) if q.size else None, nq, d, _vp(cand) if cand.size else None,
+                                   kc, int(k), _vp(idx), _vp(sc), C.byref(out_k)))
+    r = int(out_k.value)
+    return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
+
+
 def _knn_single(metric: int, query, batch: VerticalBatch, k: int, engine: int) -> BatchKnnResult:
     q = _f32(query).reshape(-1)
     _assert_dim(q, batch)

@@ -717,6 +717,100 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     return INNR_OK;
 }
 
+// Second stage of the two-stage pipeline the reference describes (scalar.rs:366-368: batch_knn_u8 first pass, then an
+// exact re-rank on the full-precision vectors): exact scores of caller-given candidates in the reference's arithmetic
+// order, ordered like the kNN functions (score order, then index ascending), best k per query.
+innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D,
+                                  const uint64_t* d_cand, size_t kc, size_t k, uint64_t* d_out_idx, float* d_out_score,
+                                  size_t* out_k) {
+    if (b && !b->V) {
+        set_error("this entry point needs an f32 batch (got a u8 code batch: use the *_u8 functions)");
+        return INNR_E_BAD_ARG;
+    }
+    if (!b || !out_k || !metric_ok(metric)) return INNR_E_BAD_ARG;
+    if (D != b->D) {
+        set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D);
+        return INNR_E_DIM_MISMATCH;
+    }
+    *out_k = 0;
+    if (b->N == 0 || k == 0 || Q == 0 || kc == 0) return INNR_OK;
+    if (kc > 256) {
+        set_error("rerank: at most 256 candidates per query (got %zu)", kc);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!d_queries || !d_cand || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
+    const size_t kout = std::min(k, kc);
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const uint32_t KP = pick_kp(kc, 0);  // 32..256
+    INNR_TRY(c->sel.ensure(Q * KP * sizeof(uint64_t)));
+    INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
+    INNR_TRY(c->q_norm.ensure(Q * sizeof(float)));
+    INNR_TRY(c->misc.ensure(Q * sizeof(uint32_t) + 64));
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
+    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+                                                                       c->q_norm.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t* bad = c->flags.as<uint32_t>() + 65;
+    rerank_prepare_kernel<<<(unsigned)((Q * KP + 255) / 256), 256, 0, c->stream>>>(d_cand, (uint32_t)Q, (uint32_t)kc, KP,
+                                                                                  (uint32_t)b->N, b->index_base,
+                                                                                  c->sel.as<uint64_t>(),
+                                                                                  c->sel_cnt.as<uint32_t>(), bad);
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t* unused = c->misc.as<uint32_t>();  // the proof flags of the kNN path: no proof to make here (cnt < KP or moot)
+#define INNR_RERANK(METV, RKV)                                                                                       \
+    rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, d_queries, b->norms,   \
+                                                                 c->q_norm.as<float>(), c->q_norm.as<float>(),       \
+                                                                 c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), KP, \
+                                                                 (uint32_t)kout, 0.0f, b->index_base, d_out_idx,     \
+                                                                 d_out_score, unused)
+    const int rk = KP <= 64 ? 1 : (KP <= 128 ? 2 : 4);
+    const int met = metric == INNR_METRIC_COSINE ? 1 : (metric == INNR_METRIC_L2SQ ? 2 : 0);
+    if (met == 1) {
+        if (rk == 1) INNR_RERANK(1, 1); else if (rk == 2) INNR_RERANK(1, 2); else INNR_RERANK(1, 4);
+    } else if (met == 2) {
+        if (rk == 1) INNR_RERANK(2, 1); else if (rk == 2) INNR_RERANK(2, 2); else INNR_RERANK(2, 4);
+    } else {
+        if (rk == 1) INNR_RERANK(0, 1); else if (rk == 2) INNR_RERANK(0, 2); else INNR_RERANK(0, 4);
+    }
+#undef INNR_RERANK
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t hbad = 0;
+    INNR_HIP_CHECK(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hbad) {
+        set_error("rerank: a candidate index lies outside this batch's range [%llu, %llu)",
+                  (unsigned long long)b->index_base, (unsigned long long)(b->index_base + b->N));
+        return INNR_E_BAD_ARG;
+    }
+    *out_k = kout;
+    return INNR_OK;
+}
+
+innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, const uint64_t* cand,
+                              size_t kc, size_t k, uint64_t* out_idx, float* out_score, size_t* out_k) {
+    if (!b || !out_k) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    if (b->N == 0 || k == 0 || Q == 0 || kc == 0) return (b->V && D != b->D) ? (set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D), INNR_E_DIM_MISMATCH) : INNR_OK;
+    if (!queries || !cand || !out_idx || !out_score) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    const size_t kout = std::min(k, kc);
+    INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
+    INNR_TRY(c->out_idx.ensure(Q * (kout + kc) * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
+    uint64_t* d_cand = c->out_idx.as<uint64_t>() + Q * kout;
+    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(hipMemcpyAsync(d_cand, cand, Q * kc * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    INNR_TRY(innr_batch_rerank_dev(b, metric, c->q_row.as<float>(), Q, D, d_cand, kc, k, c->out_idx.as<uint64_t>(),
+                                   c->out_score.as<float>(), out_k));
+    INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return INNR_OK;
+}
+
 size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
 size_t innr_batch_dimension(const innr_batch* b) { return b ? b->D : 0; }
 
@@ -987,6 +1081,60 @@ innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t s
         }
     }
     *out = b;
+    return INNR_OK;
+}
+
+// corpus ingest on the device: quantise a resident f32 batch into a u8 code batch (scalar.rs:212-225
+// per value), and QuantizationParams::fit's global range (scalar.rs:68-87) without bringing the corpus to the host
+innr_status innr_batch_quantize_u8(innr_batch* src, float alpha, float offset, innr_batch** out) {
+    if (!src || !src->V || !out) {
+        set_error("innr_batch_quantize_u8 needs an f32 batch");
+        return INNR_E_BAD_ARG;
+    }
+    innr_ctx* ctx = src->ctx;
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch_u8(ctx, src->N, src->D, alpha, offset, &b));
+    if (src->N && src->D) {
+        dim3 grid((unsigned)((b->ldN / 16 + 255) / 256), (unsigned)src->D);
+        quantize_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(src->V, src->ldN, (uint32_t)src->N, (uint32_t)src->D, offset,
+                                                           255.0f / alpha, b->C8, b->ldN);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("device quantize failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    b->index_base = src->index_base;
+    *out = b;
+    return INNR_OK;
+}
+
+innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int* out_any) {
+    if (!b || !b->V || !out_min || !out_max || !out_any) {
+        set_error("innr_batch_minmax needs an f32 batch");
+        return INNR_E_BAD_ARG;
+    }
+    innr_ctx* c = b->ctx;
+    INNR_TRY(bind_device(c));
+    *out_any = 0;
+    *out_min = 0.0f;
+    *out_max = 0.0f;
+    if (b->N == 0 || b->D == 0) return INNR_OK;
+    INNR_TRY(c->misc.ensure(4096));
+    INNR_HIP_CHECK(hipMemsetAsync(c->misc.p, 0, 8, c->stream));
+    dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+    minmax_pdx_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, c->misc.as<uint32_t>());
+    INNR_HIP_CHECK(hipGetLastError());
+    uint32_t k[2] = {0, 0};
+    INNR_HIP_CHECK(hipMemcpyAsync(k, c->misc.p, 8, hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (k[0] && k[1]) {  // at least one non-NaN value
+        *out_any = 1;
+        *out_min = ord_f32(~k[0]);
+        *out_max = ord_f32(k[1]);
+    }
     return INNR_OK;
 }
 

@@ -625,6 +625,28 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
     if (__any(bad) && lane == 0) fallback[q] = 1;
 }
 
+// Re-rank support: composites for caller-given candidate indices (any order; duplicates allowed but pointless),
+// sel[q][c] = (0 | ~idx) for c < kc, count kc. Out-of-range indices are clamped into the batch and flagged.
+__global__ void rerank_prepare_kernel(const uint64_t* __restrict__ cand, uint32_t Q, uint32_t kc, uint32_t KP, uint32_t N,
+                                      uint64_t index_base, uint64_t* __restrict__ sel, uint32_t* __restrict__ sel_cnt,
+                                      uint32_t* __restrict__ bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q * KP) return;
+    const uint32_t q = t / KP, c = t % KP;
+    if (c == 0) sel_cnt[q] = kc;
+    uint64_t v = 0;
+    if (c < kc) {
+        const uint64_t g = cand[(size_t)q * kc + c];
+        uint64_t i = g - index_base;
+        if (g < index_base || i >= N) {
+            atomicOr(bad, 1u);
+            i = 0;
+        }
+        v = cand_make(0u, (uint32_t)i);
+    }
+    sel[t] = v;
+}
+
 // L2 on the GEMM engine: per query C_j = (|q_j| + max|v|)^2 and the epilogue constant C_j - |q_j|^2 (padded queries: 0)
 __global__ void l2_query_consts_kernel(const float* __restrict__ qnorm, size_t Qpad, size_t Q, float max_norm,
                                        float* __restrict__ cq, float* __restrict__ Cj) {

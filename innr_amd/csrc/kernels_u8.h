@@ -62,6 +62,60 @@ __global__ void generate_u8_pdx_kernel(uint8_t* __restrict__ C, size_t ldN, uint
     *reinterpret_cast<uint4*>(C + (size_t)d * ldN + i16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// quantize a resident f32 batch: C[d*ldN + i] = quantize_u8(V[d*ldN + i]) (16 codes per thread); padding columns 0
+__global__ __launch_bounds__(256) void quantize_pdx_kernel(const float* __restrict__ V, size_t ldV, uint32_t N, uint32_t D,
+                                                            float offset, float inv_alpha, uint8_t* __restrict__ C,
+                                                            size_t ldN) {
+    const size_t i16 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const uint32_t d = blockIdx.y;
+    if (i16 >= ldN || d >= D) return;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);  // the two layouts pad N differently (256 vs 1024)
+        if (i16 + 4 * c4 < ldV) v = *reinterpret_cast<const float4*>(V + (size_t)d * ldV + i16 + 4 * c4);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t i = i16 + 4 * c4 + c;
+            const uint32_t q = (i < N) ? quantize_one(x[c], offset, inv_alpha) : 0u;
+            w[c4] |= q << (8 * c);
+        }
+    }
+    *reinterpret_cast<uint4*>(C + (size_t)d * ldN + i16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// QuantizationParams::fit (scalar.rs:68-87): global min and max of the stored values, NaN ignored (both of the
+// reference's comparisons are false for NaN). Keys: f32_ord (total order), so -0.0 < +0.0 -- the reference keeps
+// whichever zero it met first, the one point where a parallel reduction cannot follow a sequential scan.
+// out[0] = max over values of ~ord (i.e. min), out[1] = max of ord; both start at 0 = "nothing seen".
+__global__ __launch_bounds__(256) void minmax_pdx_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
+                                                          uint32_t* __restrict__ out) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    uint32_t kmin = 0, kmax = 0;
+    if (i4 < ldN) {
+        for (uint32_t d = blockIdx.y; d < D; d += gridDim.y) {
+            const float4 v = *reinterpret_cast<const float4*>(V + (size_t)d * ldN + i4);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (i4 + c < N && x[c] == x[c]) {
+                    const uint32_t o = f32_ord(x[c]);
+                    kmax = kmax > o ? kmax : o;
+                    kmin = kmin > ~o ? kmin : ~o;
+                }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        kmin = max(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmin) atomicMax(out + 0, kmin);
+        if (kmax) atomicMax(out + 1, kmax);
+    }
+}
+
 // query_context (scalar.rs:236-240): sum(q) folded from -0.0, and ||q|| for the GEMM engine's error bound
 __global__ void query_sums_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, size_t ldq,
                                   float* __restrict__ qsum, float* __restrict__ qnorm) {

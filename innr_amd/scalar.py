@@ -180,6 +180,14 @@ class QuantizedCorpus:
                                             C.c_float(params.alpha), C.c_float(params.offset), C.byref(h)))
         return cls(h, n, dim, params, ctx)
 
+    @classmethod
+    def from_batch(cls, batch, params: QuantizationParams) -> "QuantizedCorpus":
+        """quantize_u8 of every value of a device-resident f32 VerticalBatch, on the device (corpus ingest without a
+        host round trip); inherits the batch's index base."""
+        h = C.c_void_p()
+        check(load().innr_batch_quantize_u8(batch._h, C.c_float(params.alpha), C.c_float(params.offset), C.byref(h)))
+        return cls(h, batch.num_vectors(), batch.dimension(), params, batch._ctx)
+
     def __len__(self) -> int: return self._n
     def dimension(self) -> int: return self._d
 
@@ -222,6 +230,24 @@ class QuantizedCorpus:
             self.close()
         except Exception:
             pass
+
+
+def fit_batch(batch) -> QuantizationParams:
+    """QuantizationParams::fit (scalar.rs:68-87) over every value of a device-resident f32 VerticalBatch."""
+    mn, mx, any_ = C.c_float(0.0), C.c_float(0.0), C.c_int(0)
+    check(load().innr_batch_minmax(batch._h, C.byref(mn), C.byref(mx), C.byref(any_)))
+    if not any_.value:  # empty (scalar.rs:69-74); an all-NaN corpus leaves min > max in the reference: same result
+        return QuantizationParams(1.0, 0.0)
+    return QuantizationParams.from_range(float(mn.value), float(mx.value))
+
+
+def two_stage_knn(queries, coarse: "QuantizedCorpus", fine, k: int, k_coarse: int, metric: Optional[int] = None):
+    """The two-stage retrieval the reference describes for this module (scalar.rs:366-368): batch_knn_u8 over the
+    quantised corpus for k_coarse candidates, then an exact re-rank on the full-precision batch `fine` (both resident
+    on the GPU: 50M x 768 is 38 GB of codes + 154 GB of f32). Returns (indices [Q, k'], exact scores [Q, k'])."""
+    from . import batch as B
+    idx, _ = coarse.knn_multi(queries, k_coarse)
+    return B.batch_rerank(queries, fine, idx, k, B.METRIC_DOT if metric is None else metric)
 
 
 def batch_knn_u8(query, corpus, params: QuantizationParams, k: int, engine: int = KNN_AUTO) -> List[Tuple[int, float]]:

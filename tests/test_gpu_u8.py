@@ -110,3 +110,68 @@ def test_u8_engines_agree_large(S, innr):
     i2, s2 = qc.knn_multi(qs[:32], 10, engine=innr.KNN_EXACT)
     assert np.array_equal(i1[:32], i2) and bits_equal(s1[:32], s2)
     print(f"u8 2Mx128 256q: gemm {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms fallback {st.queries_fallback}")
+
+
+# ---------------------------------------------------------------- corpus ingest on the device, two-stage pipeline
+def test_device_quantize_and_fit_match_host(S, innr):
+    from innr_amd import batch as B
+    n, dim = 3001, 37
+    rows = (oracle.generate_uniform(n, dim, 8) * np.float32(2.5) + np.float32(0.3)).astype(np.float32)
+    rows[5, 7] = np.nan   # ignored by fit (scalar.rs:76-83: both comparisons false), quantises to 0 (`as u8`)
+    rows[9, 1] = 1e30     # saturates at 255
+    vb = B.VerticalBatch.from_rows(rows)
+    p = S.fit_batch(vb)
+    hp = oracle.qparams_fit(rows.reshape(-1))
+    assert np.float32(p.alpha).view(np.uint32) == np.float32(hp.alpha).view(np.uint32)
+    assert np.float32(p.offset).view(np.uint32) == np.float32(hp.offset).view(np.uint32)
+    p2 = S.QuantizationParams.from_range(-2.0, 3.0)
+    qc = S.QuantizedCorpus.from_batch(vb, p2)
+    assert np.array_equal(qc.codes(), oracle.quantize_u8(rows, oracle.QParams(p2.alpha, p2.offset)))
+    empty = B.VerticalBatch.from_rows(np.empty((0, 0), np.float32))
+    e = S.fit_batch(empty)
+    assert (e.alpha, e.offset) == (1.0, 0.0)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
+@pytest.mark.parametrize("n,dim,nq,kc,k", [(2000, 48, 7, 40, 10), (500, 16, 3, 256, 256), (9000, 128, 20, 100, 100)])
+def test_batch_rerank_matches_oracle(innr, metric, n, dim, nq, kc, k):
+    from innr_amd import batch as B
+    rows = oracle.generate_uniform(n, dim, 12)
+    data = oracle.from_rows(rows)
+    vb = B.VerticalBatch.from_rows(rows)
+    qs = oracle.generate_uniform(nq, dim, 13)
+    rng = np.random.default_rng(5)
+    cand = np.stack([rng.choice(n, size=kc, replace=False) for _ in range(nq)]).astype(np.uint64)
+    met = {"dot": innr.METRIC_DOT, "cos": innr.METRIC_COSINE, "l2": innr.METRIC_L2SQ}[metric]
+    idx, sc = B.batch_rerank(qs, vb, cand, k, met)
+    norms = oracle.batch_norms(data)
+    for j in range(nq):
+        full = {"dot": lambda: oracle.batch_dot(qs[j], data), "cos": lambda: oracle.batch_cosine(qs[j], data, norms),
+                "l2": lambda: oracle.batch_l2_squared(qs[j], data)}[metric]()
+        c = np.sort(cand[j].astype(np.int64))  # index asc, then a stable sort by score: the kNN functions' order
+        s = full[c]
+        order = np.argsort(s.astype(np.float64) if metric == "l2" else -s.astype(np.float64), kind="stable")[:k]
+        assert idx[j].tolist() == c[order].tolist() and bits_equal(sc[j], s[order]), (metric, j)
+    with pytest.raises(innr.InnrError):
+        B.batch_rerank(qs, vb, np.full((nq, 4), n + 5, np.uint64), 2, met)  # outside the batch
+
+
+def test_two_stage_pipeline_u8_then_exact(S, innr):
+    from innr_amd import batch as B
+    n, dim, nq, k, kc = 200_000, 96, 64, 10, 100
+    vb = B.VerticalBatch.generate(n, dim, seed=3)
+    p = S.fit_batch(vb)
+    qc = S.QuantizedCorpus.from_batch(vb, p)
+    gen = S.QuantizedCorpus.generate(n, dim, p, seed=3)
+    assert np.array_equal(qc.codes()[:2000], gen.codes()[:2000])  # device quantise(resident f32) == quantise(generator)
+    qs = oracle.generate_uniform(nq, dim, 21)
+    idx, sc = S.two_stage_knn(qs, qc, vb, k, kc)
+    ei, es = B.batch_knn_dot_multi(qs, vb, k, engine=innr.KNN_EXACT)
+    # exact scores, and with 10x over-fetch the 8-bit first pass loses nothing of the true top-10 on this data
+    recall = np.mean([len(set(idx[j].tolist()) & set(ei[j].tolist())) / k for j in range(nq)])
+    assert recall >= 0.99, recall
+    for j in range(nq):
+        common = [i for i in idx[j].tolist() if i in set(ei[j].tolist())]
+        pos = {int(i): t for t, i in enumerate(ei[j].tolist())}
+        got = {int(i): t for t, i in enumerate(idx[j].tolist())}
+        assert all(sc[j][got[i]].view(np.uint32) == es[j][pos[i]].view(np.uint32) for i in common)

@@ -51,6 +51,40 @@ def _gpu_local_search(batch, metric: int, engine: int):
     return run
 
 
+def _gpu_local_search_u8(qcorpus, engine: int):
+    """Shard-local batch_knn_u8 (scalar.rs:370-393) with device-resident queries and results."""
+    import torch
+
+    def run(queries: "torch.Tensor", k: int, stats: Optional[KnnStats] = None):
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq, d = queries.shape
+        kk = min(int(k), len(qcorpus))
+        idx = torch.empty((nq, max(kk, 1)), dtype=torch.int64, device=queries.device)
+        sc = torch.empty((nq, max(kk, 1)), dtype=torch.float32, device=queries.device)
+        out_k = C.c_size_t(0)
+        st = stats if stats is not None else KnnStats()
+        check(load().innr_batch_knn_u8_dev(qcorpus._h, C.c_void_p(queries.data_ptr()), nq, d, int(k), engine,
+                                           C.c_void_p(idx.data_ptr()), C.c_void_p(sc.data_ptr()), C.byref(out_k),
+                                           C.byref(st)))
+        return idx[:, :out_k.value], sc[:, :out_k.value]
+
+    return run
+
+
+def _gpu_local_search_docs(corpus, cosine: bool, engine: int):
+    """Shard-local maxsim top-k: `queries` is ONE query's token matrix [Tq, dim]; returns [1, k'] blocks."""
+    import torch
+
+    def run(query_tokens: "torch.Tensor", k: int, stats: Optional[KnnStats] = None):
+        q = query_tokens.detach().cpu().numpy()  # Tq x dim floats: the entry point takes the query from the host
+        idx, sc = corpus.topk(q, k, cosine=cosine, stats=stats, engine=engine)
+        dev = query_tokens.device
+        return (torch.from_numpy(idx.astype(np.int64)).reshape(1, -1).to(dev),
+                torch.from_numpy(sc).reshape(1, -1).to(dev))
+
+    return run
+
+
 def _gpu_merge(ctx: _lib.Context, metric: int):
     import torch
 
@@ -89,13 +123,29 @@ class ShardedKnn:
         self.local_search = _gpu_local_search(batch, metric, engine)
         self.merge = _gpu_merge(batch._ctx, metric)
 
+    def attach_gpu_u8(self, qcorpus, engine: int = KNN_AUTO) -> None:
+        """Shard = a device-resident QuantizedCorpus holding documents [start, start+count) (scalar::batch_knn_u8)."""
+        assert len(qcorpus) == self.count
+        qcorpus.set_index_base(self.start)
+        self.local_search = _gpu_local_search_u8(qcorpus, engine)
+        self.merge = _gpu_merge(qcorpus._ctx, METRIC_DOT)
+
+    def attach_gpu_docs(self, corpus, cosine: bool = False, engine: int = KNN_AUTO) -> None:
+        """Shard = a device-resident maxsim DocumentCorpus holding documents [start, start+count); search() then takes
+        ONE query's token matrix and returns [1, k] blocks."""
+        assert len(corpus) == self.count
+        corpus.set_index_base(self.start)
+        self.local_search = _gpu_local_search_docs(corpus, cosine, engine)
+        self.merge = _gpu_merge(corpus._ctx, METRIC_DOT)
+        self._one_query = True
+
     def search(self, queries, k: int, stats: Optional[KnnStats] = None):
         """queries: [Q, D] tensor on this rank's device (identical on every rank). Returns the global top-k:
         (indices int64 [Q, k'], scores float32 [Q, k']) with k' = min(k, n_total), identical on every rank."""
         import torch
         kout = min(int(k), self.n_total)
         idx, sc = self.local_search(queries, k, stats) if stats is not None else self.local_search(queries, k)
-        nq = queries.shape[0]
+        nq = 1 if getattr(self, "_one_query", False) else queries.shape[0]
         # pad to a fixed [Q, kin] block so every rank gathers the same shape (a shard may hold < k vectors)
         kin = min(int(k), max(shard_range(self.n_total, self.world, r)[1] for r in range(self.world)))
         kin = max(kin, 1)

@@ -88,6 +88,10 @@ class DocumentCorpus:
         check(load().innr_maxsim_generate(ctx.handle, ndocs, T, dim, C.c_uint64(seed), C.c_uint64(row0), C.byref(h)))
         return cls(h, ndocs, T, dim, ctx)
 
+    def set_index_base(self, base: int) -> None:
+        """Global index of this shard's first document (multi-GPU range partition)."""
+        check(load().innr_docs_set_index_base(self._h, C.c_uint64(int(base))))
+
     def __len__(self) -> int:
         return self._n
 

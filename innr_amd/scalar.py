@@ -191,6 +191,10 @@ class QuantizedCorpus:
     def __len__(self) -> int: return self._n
     def dimension(self) -> int: return self._d
 
+    def set_index_base(self, base: int) -> None:
+        """Global index of this shard's first document (multi-GPU range partition)."""
+        check(load().innr_batch_set_index_base(self._h, C.c_uint64(int(base))))
+
     def codes(self) -> np.ndarray:
         """Codes back on the host as (n, dim) rows."""
         out = np.empty((self._d, self._n), dtype=np.uint8)

@@ -51,3 +51,67 @@ def test_logical_shards_merge_equals_whole_corpus(metric_name, g, n_total, k):
     for vb in shards:
         vb.close()
     ctx.close()
+
+
+def test_logical_shards_u8_and_maxsim():
+    """the same merge contract for the other two sharded paths: scalar::batch_knn_u8 and maxsim top-k"""
+    import torch
+    import innr_amd
+    from innr_amd import maxsim as M
+    from innr_amd import scalar as S
+    from innr_amd.dist import (INVALID_INDEX, _gpu_local_search_docs, _gpu_local_search_u8, _gpu_merge, shard_range)
+
+    ctx = innr_amd.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    merge = _gpu_merge(ctx, innr_amd.METRIC_DOT)
+
+    # u8: 3 shards of a 30K x 64 code corpus
+    g, n_total, dim, nq, k = 3, 30_000, 64, 40, 20
+    p = S.QuantizationParams.from_range(-1.0, 1.0)
+    queries = oracle.generate_uniform(nq, dim, 5)
+    q_dev = torch.from_numpy(queries).to(dev)
+    all_i = torch.full((g, nq, k), INVALID_INDEX, dtype=torch.int64, device=dev)
+    all_s = torch.zeros((g, nq, k), dtype=torch.float32, device=dev)
+    keep = []
+    for r in range(g):
+        start, count = shard_range(n_total, g, r)
+        qc = S.QuantizedCorpus.generate(count, dim, p, seed=4, row0=start, ctx=ctx)
+        qc.set_index_base(start)
+        keep.append(qc)
+        idx, sc = _gpu_local_search_u8(qc, innr_amd.KNN_AUTO)(q_dev, k)
+        all_i[r, :, :idx.shape[1]] = idx
+        all_s[r, :, :sc.shape[1]] = sc
+    out_i, out_s = merge(all_i, all_s, k)
+    torch.cuda.synchronize()
+    codes = oracle.quantize_u8(oracle.generate_uniform(n_total, dim, 4), oracle.QParams(p.alpha, p.offset))
+    for j in range(nq):
+        oi, os_ = oracle.batch_knn_u8(queries[j], codes, oracle.QParams(p.alpha, p.offset), k)
+        assert out_i[j].cpu().numpy().tolist() == oi.astype(np.int64).tolist()
+        assert np.array_equal(out_s[j].cpu().numpy().view(np.uint32), os_.view(np.uint32))
+
+    # maxsim: 4 shards of 6000 documents x 32 tokens x 64 dims, one 8-token query
+    g, ndocs, T, dim, Tq, k = 4, 6000, 32, 64, 8, 15
+    whole = M.DocumentCorpus.generate(ndocs, T, dim, seed=9, ctx=ctx)
+    rq = oracle.generate_uniform(Tq, dim, 77)
+    q = (rq / np.sqrt((rq.astype(np.float64) ** 2).sum(axis=1, keepdims=True))).astype(np.float32)
+    want_i, want_s = whole.topk(q, k, engine=innr_amd.KNN_EXACT)
+    q_dev = torch.from_numpy(q).to(dev)
+    all_i = torch.full((g, 1, k), INVALID_INDEX, dtype=torch.int64, device=dev)
+    all_s = torch.zeros((g, 1, k), dtype=torch.float32, device=dev)
+    for r in range(g):
+        start, count = shard_range(ndocs, g, r)
+        dc = M.DocumentCorpus.generate(count, T, dim, seed=9, row0=start * T, ctx=ctx)
+        dc.set_index_base(start)
+        keep.append(dc)
+        idx, sc = _gpu_local_search_docs(dc, False, innr_amd.KNN_AUTO)(q_dev, k)
+        all_i[r, :, :idx.shape[1]] = idx
+        all_s[r, :, :sc.shape[1]] = sc
+    out_i, out_s = merge(all_i, all_s, k)
+    torch.cuda.synchronize()
+    assert out_i[0].cpu().numpy().tolist() == want_i.astype(np.int64).tolist()
+    assert np.array_equal(out_s[0].cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+    for o in keep:
+        o.close()
+    whole.close()
+    ctx.close()

@@ -166,3 +166,28 @@ def test_maxsim_c4_shape_properties(M):
         assert idx.tolist() == order.tolist() and bits_equal(sc, allsc[order])
         print(f"maxsim 100Kx64x128 Tq=32 {name}: scan {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms -> "
               f"{ndocs*T*dim*4/st.gemm_ms/1e6:.0f} GB/s, engine {st.engine} fallback {st.queries_fallback}")
+
+
+def test_full_size_properties_c4(M):
+    # BASELINE.json configs[3]: 1M documents x 64 tokens x 128 dims, one 32-token query, top-100: both engines agree
+    # bitwise; sorted, unique; scores of sampled winners re-derived by the oracle from the regenerated documents.
+    import innr_amd
+    ndocs, T, dim, Tq, k = 1_000_000, 64, 128, 32, 100
+    dc = M.DocumentCorpus.generate(ndocs, T, dim, seed=0)
+    q = _tokens(1, Tq, dim, 123)[0]
+    st = innr_amd.KnnStats()
+    idx, sc = dc.topk(q, k, engine=innr_amd.KNN_MFMA, stats=st)
+    assert st.engine == innr_amd.KNN_MFMA and st.queries_fallback == 0
+    i2, s2 = dc.topk(q, k, engine=innr_amd.KNN_EXACT)
+    assert np.array_equal(idx, i2) and bits_equal(sc, s2)
+    assert np.all(sc[:-1] >= sc[1:]) and len(set(idx.tolist())) == k and int(idx.max()) < ndocs
+    for r in (0, 57, 99):  # regenerate the winner's tokens exactly as generate_tokens_kernel does
+        rows = oracle.generate_uniform(T, dim, 0, row0=int(idx[r]) * T)
+        toks = np.empty_like(rows)
+        for t in range(T):
+            ss = np.float32(-0.0)
+            for x in rows[t]:
+                ss = np.float32(ss + np.float32(x * x))
+            toks[t] = rows[t] / np.float32(np.sqrt(ss))
+        assert np.float32(oracle.maxsim(q, toks)).view(np.uint32) == sc[r].view(np.uint32)
+    print(f"C4 maxsim: scan {st.gemm_ms:.2f} ms, total {st.total_ms:.2f} ms")

@@ -175,3 +175,27 @@ def test_two_stage_pipeline_u8_then_exact(S, innr):
         pos = {int(i): t for t, i in enumerate(ei[j].tolist())}
         got = {int(i): t for t, i in enumerate(idx[j].tolist())}
         assert all(sc[j][got[i]].view(np.uint32) == es[j][pos[i]].view(np.uint32) for i in common)
+
+
+def test_full_size_properties_c3(S, innr):
+    # BASELINE.json configs[2]: 50M x 768 u8 codes, 1024 queries, k = 100 -- through size-independent properties:
+    # the GEMM engine equals the bit-exact engine on a query subset; results sorted, unique, in range; few redone.
+    n, dim, nq, k = 50_000_000, 768, 1024, 100
+    p = S.QuantizationParams.from_range(-1.0, 1.0)
+    qc = S.QuantizedCorpus.generate(n, dim, p, seed=0)
+    qs = oracle.generate_uniform(nq, dim, 0xBE7C)
+    st = innr.KnnStats()
+    idx, sc = qc.knn_multi(qs, k, engine=innr.KNN_MFMA, stats=st)
+    assert idx.shape == (nq, k) and st.engine == innr.KNN_MFMA and st.queries_fallback <= 8, st.queries_fallback
+    assert np.all(sc[:, :-1] >= sc[:, 1:]) and int(idx.max()) < n
+    assert all(len(set(r.tolist())) == k for r in idx[::37])
+    i2, s2 = qc.knn_multi(qs[:8], k, engine=innr.KNN_EXACT)
+    assert np.array_equal(idx[:8], i2) and bits_equal(sc[:8], s2)
+    # spot check of the scores themselves: the oracle's asymmetric dot on the winners' regenerated codes
+    op = oracle.QParams(p.alpha, p.offset)
+    for j in (0, 511):
+        for r in (0, k - 1):
+            row = oracle.generate_uniform(1, dim, 0, row0=int(idx[j, r]))
+            code = oracle.quantize_u8(row, op)[0]
+            assert np.float32(oracle.asymmetric_dot_u8(qs[j], code, op)).view(np.uint32) == sc[j, r].view(np.uint32)
+    print(f"C3 u8: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")

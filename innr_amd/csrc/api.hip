@@ -302,7 +302,7 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
 // ---- GEMM engine -------------------------------------------------------------------------------------
 struct GemmPlan {
     size_t Qpad;
-    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, stagger;
+    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks;
 };
 
 static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
@@ -325,8 +325,6 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
     // bridge, so co-locating query tiles buys no corpus reuse and only evicts queries. Same speed either way.
     uint32_t want = 1;
     if (const char* e = getenv("INNR_GEMM_QT_GROUP")) want = (uint32_t)std::max(1, atoi(e));
-    p.stagger = 0;
-    if (const char* e = getenv("INNR_GEMM_STAGGER")) p.stagger = (uint32_t)std::max(0, atoi(e));
     p.qtg = p.nqt;
     for (uint32_t g = std::min(want, p.nqt); g <= p.nqt; ++g)
         if (p.nqt % g == 0 && 8 % (p.nqt / g) == 0) {
@@ -352,7 +350,7 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     gemm_filter_kernel<KIND, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
         p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
-        ld_dump, p.stagger)
+        ld_dump)
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;
         case 512: INNR_GEMM_LAUNCH(8); break;

@@ -5,8 +5,7 @@
 // (:756-758) / batch_cosine_into epilogue (:713-727)  for a whole batch of queries.
 //
 // Roofline: MFMA-bound. 2*Q*N*D flop; v_mfma_f32_32x32x2_f32 = 64 flop/clk/SIMD = 157.3 TFLOP/s chip peak.
-// Arithmetic intensity at a 128 x 256 block tile is 2*128*256/(4*(128+256)) = 42.7 flop/B against L2, and
-// the corpus itself is streamed from HBM once per query tile (<= Q/256 times): far below the HBM roof.
+// The corpus is streamed once per query tile (<= Q/256 times): far below the HBM roof.
 //
 // Mapping (CDNA4, wave64):
 //   S^T[corpus i][query j] = sum_d V[d][i] * Qt[d][j]     A = corpus (MFMA rows), B = queries (MFMA cols)
@@ -15,14 +14,14 @@
 //   once per call to Qt[d*Qpad + j]. No in-kernel transpose, every global and LDS access is contiguous.
 //   Block = 256 threads = 4 waves, tile 128 corpus x 256 queries x BK 16; wave w owns queries [64w, 64w+64)
 //   x all 128 corpus rows = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs).
-//   One ds_read_b128 per lane yields the A fragments of FOUR row tiles at once (tile rt holds corpus rows
-//   4r+rt), one ds_read_b64 the B fragments of TWO column tiles (tile ct holds queries 2c+ct): 2 LDS reads
-//   per 8 MFMAs, conflict-free (each wave instruction reads 1 KiB / 512 B of contiguous LDS).
-//   Staging: global_load_lds_dwordx4 (LDS-DMA), two LDS stages of 24 KiB, one barrier per K-step; 48 KiB LDS
-//   and <= 256 VGPRs keep two blocks resident per CU, so one block's epilogue (VALU) overlaps the other's
-//   MFMAs. The wave that owns a query owns its candidate list: no cross-wave synchronisation in the epilogue.
-//   Block -> (slice, query tile) is chosen so the query tiles of one corpus slice share an XCD (L2 reuse of
-//   the streamed corpus tile); placement only affects speed.
+//   Corpus tile (shared by the 4 waves): LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring of 8 KiB, two
+//   K-steps ahead; one ds_read_b128 per lane yields the A fragments of FOUR row tiles at once (tile rt holds
+//   corpus rows 4r+rt), conflict-free. Query operands (private to a wave): plain 8-byte loads from the L2-resident
+//   Qt straight into registers, one K-step ahead -- they never touch LDS. One barrier per K-step; 26 KiB LDS and
+//   <= 256 VGPRs keep two blocks resident per CU, so one block's epilogue (VALU) overlaps the other's MFMAs.
+//   The wave that owns a query owns its candidate list: no cross-wave synchronisation in the epilogue.
+//   Block -> (slice, query tile): one query tile per XCD group (its 768 KiB stay in that L2); placement only
+//   affects speed.
 #pragma once
 
 #include "common.h"
@@ -126,8 +125,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
-    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump,
-    uint32_t stagger) {
+    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
@@ -152,11 +150,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     const uint32_t nk = Dpad / kBK;
     const uint32_t total = (t1 - t0) * nk;
 
-    // The two blocks that share a CU run the same K-step loop at the same rate (they alternate on the MFMA pipe), so
-    // left alone they reach their barriers and LDS-latency bubbles together and nothing covers them. The second half
-    // of the grid (the blocks dispatched into the second slot of each CU) starts `stagger` x 64 cycles late.
-    if (blockIdx.x >= gridDim.x / 2)
-        for (uint32_t i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
     s.cnt[threadIdx.x] = 0;  // kBQ == kGemmThreads
     s.thr[threadIdx.x] = 0;
     uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;

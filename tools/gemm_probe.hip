@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(gs, 0, (Qpad * KP + Qpad) * 4));
         hipEventRecord(a);
         gemm_filter_kernel<kGemmDot, 6, 0><<<nqt * ns, kGemmThreads>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
-                                                                       1.0f, lists, counts, KP, err, gs, gs + Qpad * KP, nullptr, 0, 0);
+                                                                       1.0f, lists, counts, KP, err, gs, gs + Qpad * KP, nullptr, 0);
         hipEventRecord(b); CK(hipEventSynchronize(b));
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;

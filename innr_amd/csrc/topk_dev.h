@@ -110,15 +110,4 @@ __device__ __forceinline__ uint32_t wave_compact(uint64_t* list, uint32_t cnt, u
     return keep;
 }
 
-// Dispatch on the list capacity (cap = 64*R; cap = cand_cap(KP) for KP in {32,64,128,256}).
-__device__ __forceinline__ uint32_t wave_compact_dyn(uint64_t* list, uint32_t cnt, uint32_t KP, uint32_t cap,
-                                                     uint32_t* thr_pref) {
-    switch (cap) {
-        case 384: return wave_compact<6>(list, cnt, KP, thr_pref);
-        case 512: return wave_compact<8>(list, cnt, KP, thr_pref);
-        case 768: return wave_compact<12>(list, cnt, KP, thr_pref);
-        default: return wave_compact<20>(list, cnt, KP, thr_pref);  // 1280
-    }
-}
-
 }  // namespace innr

@@ -1563,7 +1563,7 @@ static innr_status maxsim_ensure_token_norms(innr_docs* d) {
     if (d->tok_inv) return INNR_OK;
     innr_ctx* c = d->ctx;
     const size_t ntok = d->ndocs * d->T;
-    hipError_t e = hipMalloc((void**)&d->tok_inv, std::max<size_t>(ntok, 1) * sizeof(float));
+    hipError_t e = hipMalloc((void**)&d->tok_inv, (ntok + 64) * sizeof(float));  // + slack: tiles read 4-float groups past T
     if (e != hipSuccess) {
         d->tok_inv = nullptr;
         set_error("hipMalloc(%zu bytes) for token norms failed: %s", ntok * sizeof(float), hipGetErrorString(e));
@@ -1625,7 +1625,26 @@ static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok,
         const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
         maxsim_pack_mfma_kernel<<<(unsigned)((dim * 32 + 255) / 256), 256, 0, c->stream>>>(c->q_row.as<float>() + p0 * dim,
                                                                                           (uint32_t)dim, qB);
-        if (cosine)
+#define INNR_MS_TILE(COSV, NBV)                                                                                         \
+    maxsim_mfma_tile_kernel<COSV, NBV><<<blocks, kMsThreads, lds, c->stream>>>(                                           \
+        d->tok, d->doc_len, COSV ? d->tok_inv : nullptr, (uint32_t)d->ndocs, (uint32_t)d->T, qB, nq,                      \
+        COSV ? qscale + p0 : nullptr, approx, approx, p0 == 0)
+        const bool tiled = dim % 32 == 0 && dim <= 128 && !getenv("INNR_MAXSIM_GENERIC");
+        if (tiled && cosine) {
+            switch (dim / 32) {
+                case 1: INNR_MS_TILE(true, 1); break;
+                case 2: INNR_MS_TILE(true, 2); break;
+                case 3: INNR_MS_TILE(true, 3); break;
+                default: INNR_MS_TILE(true, 4); break;
+            }
+        } else if (tiled) {
+            switch (dim / 32) {
+                case 1: INNR_MS_TILE(false, 1); break;
+                case 2: INNR_MS_TILE(false, 2); break;
+                case 3: INNR_MS_TILE(false, 3); break;
+                default: INNR_MS_TILE(false, 4); break;
+            }
+        } else if (cosine)
             maxsim_mfma_kernel<true><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, d->tok_inv, (uint32_t)d->ndocs,
                                                                              (uint32_t)d->T, (uint32_t)dim, qB, nq, qscale + p0,
                                                                              approx, approx, p0 == 0);
@@ -1633,6 +1652,7 @@ static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok,
             maxsim_mfma_kernel<false><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, nullptr, (uint32_t)d->ndocs,
                                                                               (uint32_t)d->T, (uint32_t)dim, qB, nq, nullptr,
                                                                               approx, approx, p0 == 0);
+#undef INNR_MS_TILE
         INNR_HIP_CHECK(hipGetLastError());
     }
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));

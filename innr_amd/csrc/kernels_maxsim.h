@@ -378,6 +378,116 @@ __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_kernel(
     }
 }
 
+// ---- MFMA engine, tile-unrolled variant for dim = 32 * NB, NB <= 4 (ColBERT's 128) ------------------------------
+// Same mathematics as maxsim_mfma_kernel; the difference is the memory pipeline. The generic kernel lets the compiler
+// place the waits and ends every 32-dim burst on s_waitcnt vmcnt(0) + 16 register moves (its next-burst buffer is
+// copied into the current one), i.e. one burst of lead. Here a whole 32-token tile lives in NB x 4 float4 registers per
+// lane, every (tile, burst) has its own registers, and burst b of the NEXT tile is requested the moment burst b of the
+// current one has been multiplied: NB-1 bursts of lead across tile and document boundaries. All loads are plain C
+// (every VMEM op visible to the compiler, no register copies of in-flight loads), so hipcc's own s_waitcnt vmcnt(N)
+// comes out as the exact count of younger requests; past its last tile a wave re-requests the current one (mapped
+// addresses, registers nobody reads) so that the loop body is branch-free.
+template <bool COS, int NB>
+__global__ __launch_bounds__(kMsThreads) void maxsim_mfma_tile_kernel(
+    const float* __restrict__ tok, const uint32_t* __restrict__ doc_len, const float* __restrict__ tok_inv /*COS, padded*/,
+    uint32_t ndocs, uint32_t T, const float* __restrict__ qB /*[4*NB][64][4]*/, uint32_t nq,
+    const float* __restrict__ q_scale /*[32] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
+    bool first_pass) {
+    constexpr uint32_t dim = 32 * NB, nch = 4 * NB;
+    extern __shared__ __attribute__((aligned(16))) float s_qB[];
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < nch * 64; i += kMsThreads)
+        reinterpret_cast<float4*>(s_qB)[i] = reinterpret_cast<const float4*>(qB)[i];
+    __syncthreads();
+    const float4* bl = reinterpret_cast<const float4*>(s_qB) + lane;
+    // wave index as an SGPR value: document bookkeeping (lengths, loop control) then stays on the scalar unit --
+    // as a VGPR value the doc_len read became a vector load whose use drained every token load in flight
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kMsThreads + threadIdx.x) >> 6);
+    const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
+    const uint32_t j = lane & 31, h = lane >> 5;
+    const float qs = COS ? q_scale[j] : 1.0f;
+    if (wave >= ndocs) return;  // wave-uniform, after the only barrier
+    auto doclen = [&](uint32_t d) { return doc_len ? min(doc_len[d], T) : T; };
+    // rows past the document's end re-read its last token (mapped memory) and are masked out of the max
+    auto rowptr = [&](uint32_t d, uint32_t t0) { return tok + ((size_t)d * T + min(t0 + j, T - 1)) * dim + 4 * h; };
+    auto invptr = [&](uint32_t d, uint32_t t0, int q) { return tok_inv + (size_t)d * T + t0 + 8 * q + 4 * h; };
+    // 4 consecutive floats at a 4-byte-aligned address (doc*T need not be a multiple of 4)
+    auto ldinv = [&](const float* p) { return make_float4(p[0], p[1], p[2], p[3]); };
+
+    uint32_t cdoc = wave, ct0 = 0, clen = doclen(cdoc);
+    const float* rp = rowptr(cdoc, 0);
+    float4 a[NB][4], iv[4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[b][u] = *reinterpret_cast<const float4*>(rp + 32 * b + 8 * u);
+    if (COS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) iv[q] = ldinv(invptr(cdoc, 0, q));
+    }
+    float best = -INFINITY;
+    while (true) {  // every exit condition is wave-uniform
+        uint32_t ndoc = cdoc, nt0 = ct0 + 32, nlen = clen;
+        if (nt0 >= clen) {
+            ndoc = cdoc + nwaves;
+            nt0 = 0;
+            nlen = ndoc < ndocs ? doclen(ndoc) : 0;
+        }
+        const bool has_next = ndoc < ndocs;
+        const float* nrp = has_next ? rowptr(ndoc, nt0) : rp;
+        msf32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b4 = bl[(size_t)(4 * b + u) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].w, b4.w, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[b][u] = *reinterpret_cast<const float4*>(nrp + 32 * b + 8 * u);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const uint32_t row = ct0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            float v = acc[g];
+            if (COS) {
+                const float4 t = iv[g >> 2];
+                v *= (g & 3) == 0 ? t.x : ((g & 3) == 1 ? t.y : ((g & 3) == 2 ? t.z : t.w));
+            }
+            m = (row < clen) ? fmaxf(m, v) : m;
+        }
+        if (COS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) iv[q] = ldinv(has_next ? invptr(ndoc, nt0, q) : invptr(cdoc, ct0, q));
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        best = fmaxf(best, m);
+        if (ndoc != cdoc) {  // last tile of this document: sum over query tokens, publish
+            float v = (j < nq) ? best * qs : 0.0f;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) {
+                float total = (first_pass ? 0.0f : partial_in[cdoc]) + v;
+                if (total != total) total = INFINITY;  // a NaN anywhere: force the document into the exact re-score
+                out[cdoc] = (clen == 0) ? 0.0f : total;
+            }
+            best = -INFINITY;
+        }
+        if (!has_next) break;
+        cdoc = ndoc;
+        ct0 = nt0;
+        clen = nlen;
+        rp = nrp;
+    }
+}
+
 // Re-score epilogue (one block of 256 threads, ncand <= 256): order the candidates by (exact score desc, document
 // index asc), emit the best kout, and PROVE them: every document outside the candidate set has approximate score
 // <= t_approx (the worst candidate's), hence exact score <= t_approx + E; if the kout-th exact score is strictly

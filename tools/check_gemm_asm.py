@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Build-time guard for the hand-counted waits in gemm_filter_kernel (innr_amd/csrc/kernels_gemm.h).
+
+The query operands are loaded by inline asm (`global_load_dwordx2`) and become valid only at the matching
+`s_waitcnt vmcnt(N)` asm, which ties the registers with "+v". If the register allocator ever satisfied such a tie by
+COPYING a register (copy before the wait = stale data), results would be silently wrong on some runs. This script reads
+the ISA (`make -C innr_amd/csrc asm`) and fails unless, in every instantiation, the 8 operand register pairs are touched
+only by: the asm loads themselves, MFMAs, their zero-initialisation, and address temporaries that feed the very next
+load of the same pair.
+
+    make -C innr_amd/csrc asm && python tools/check_gemm_asm.py
+"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
+s = open(path).read()
+names = [n for n in re.findall(r"^(_ZN4innr18gemm_filter_kernel\S+):", s, flags=re.M) if not n.endswith(".kd")]
+if not names:
+    sys.exit("no gemm_filter_kernel in " + path)
+bad_total = 0
+for name in names:
+    i = s.index("\n" + name + ":")
+    body = s[i:s.index("s_endpgm", i)].split("\n")
+    pairs = set()
+    for k, line in enumerate(body):
+        if ";;#ASMSTART" in line and k + 1 < len(body):
+            m = re.match(r"\s*global_load_dwordx2 v\[(\d+):(\d+)\]", body[k + 1])
+            if m:
+                pairs.add((int(m.group(1)), int(m.group(2))))
+    flat = {r for a, b in pairs for r in range(a, b + 1)}
+    bad = []
+    for k, line in enumerate(body):
+        t = line.split(";")[0].strip()
+        if not t or t.startswith("."):
+            continue
+        op = t.split()[0]
+        if op.startswith(("v_mfma", "global_load_dwordx2", "s_")):
+            continue
+        used = set()
+        for mm in re.finditer(r"v\[(\d+):(\d+)\]", t):
+            used.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        for mm in re.finditer(r"\bv(\d+)\b", t):
+            used.add(int(mm.group(1)))
+        if not (used & flat):
+            continue
+        ops = [p.strip() for p in t[len(op):].split(",")]
+        dst = ops[0]
+        # allowed: writes (zero-init, temporaries while the pair is dead); a READ of an operand register is not
+        srcs = ",".join(ops[1:])
+        src_regs = set()
+        for mm in re.finditer(r"v\[(\d+):(\d+)\]", srcs):
+            src_regs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+        for mm in re.finditer(r"\bv(\d+)\b", srcs):
+            src_regs.add(int(mm.group(1)))
+        if src_regs & flat:
+            # reading a pair as the ADDRESS of its own reload (v_lshl_add_u64 vX, vX ... ; global_load vX, vX) is fine
+            nxt = " ".join(body[k + 1:k + 4])
+            if op.startswith("v_lshl_add_u64") and re.search(r"global_load_dwordx2 " + re.escape(dst), nxt):
+                continue
+            bad.append(t)
+    short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3>", name)
+    status = "ok" if (len(pairs) == 8 and not bad) else "FAIL"
+    print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads  {status}")
+    for b in bad[:5]:
+        print("     ", b)
+    bad_total += (len(pairs) != 8) + len(bad)
+sys.exit(1 if bad_total else 0)

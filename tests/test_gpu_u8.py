@@ -199,3 +199,39 @@ def test_full_size_properties_c3(S, innr):
             code = oracle.quantize_u8(row, op)[0]
             assert np.float32(oracle.asymmetric_dot_u8(qs[j], code, op)).view(np.uint32) == sc[j, r].view(np.uint32)
     print(f"C3 u8: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")
+
+
+def test_rerank_and_ingest_edge_cases(S, innr):
+    from innr_amd import batch as B
+    rows = oracle.generate_uniform(50, 8, 2)
+    vb = B.VerticalBatch.from_rows(rows)
+    q = oracle.generate_uniform(2, 8, 3)
+    # k larger than the candidate list: everything comes back, ordered; k = 0 / no candidates: empty
+    idx, sc = B.batch_rerank(q, vb, np.array([[7, 3, 9], [1, 2, 4]], np.uint64), 10)
+    assert idx.shape == (2, 3) and np.all(sc[:, :-1] >= sc[:, 1:])
+    assert sorted(idx[0].tolist()) == [3, 7, 9]
+    idx, sc = B.batch_rerank(q, vb, np.array([[7, 3, 9], [1, 2, 4]], np.uint64), 0)
+    assert idx.shape[1] == 0
+    idx, sc = B.batch_rerank(q, vb, np.empty((2, 0), np.uint64), 5)
+    assert idx.shape[1] == 0
+    with pytest.raises(innr.InnrPanic):
+        B.batch_rerank(np.ones((2, 9), np.float32), vb, np.array([[1], [2]], np.uint64), 1)  # dimension mismatch
+    with pytest.raises(innr.InnrError):
+        B.batch_rerank(q, vb, np.zeros((2, 300), np.uint64), 1)  # more than 256 candidates
+    # index base: candidates are GLOBAL indices
+    vb.set_index_base(1000)
+    idx, sc = B.batch_rerank(q[:1], vb, np.array([[1007, 1003]], np.uint64), 2)
+    assert sorted(idx[0].tolist()) == [1003, 1007]
+    with pytest.raises(innr.InnrError):
+        B.batch_rerank(q[:1], vb, np.array([[7]], np.uint64), 1)  # below the base
+    vb.set_index_base(0)
+    # quantising an all-NaN / constant corpus: fit falls back to (1, 0) / alpha 1 (scalar.rs:57)
+    nanb = B.VerticalBatch.from_rows(np.full((4, 3), np.nan, np.float32))
+    p = S.fit_batch(nanb)
+    assert (p.alpha, p.offset) == (1.0, 0.0)
+    assert np.all(S.QuantizedCorpus.from_batch(nanb, p).codes() == 0)
+    const = B.VerticalBatch.from_rows(np.full((4, 3), 2.5, np.float32))
+    p = S.fit_batch(const)
+    assert (p.alpha, p.offset) == (1.0, 2.5)
+    with pytest.raises(innr.InnrError):
+        S.QuantizedCorpus.from_batch(S.QuantizedCorpus.from_codes(np.zeros((2, 2), np.uint8), 2, 2, p), p)  # not an f32 batch

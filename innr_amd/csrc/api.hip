@@ -59,6 +59,18 @@ struct innr_ctx {
     bool own_stream = false;
     int num_cus = 256;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Pinned staging for SMALL host<->device transfers (queries in, top-k out, flags): a hipMemcpyAsync on pageable
+    // memory costs ~40 us per call on this stack, four of them made a single-query call 190 us; through pinned
+    // memory the same copies are a few us. Inputs are staged by copy_in (bump allocation), outputs land in the
+    // pinned area and are handed to the caller's buffers by ctx_sync, which every host-pointer entry point ends on.
+    char* pin = nullptr;
+    size_t pin_in_off = 0, pin_out_off = 0;
+    struct PendingOut {
+        void* user;
+        const void* staged;
+        size_t bytes;
+    };
+    std::vector<PendingOut> pending;
     // workspace
     DevBuf q_row;     // queries row-major [Q][ldq]
     DevBuf q_kmajor;  // queries K-major [Dpad][Qpad] for the GEMM engine
@@ -77,6 +89,43 @@ struct innr_ctx {
     DevBuf out_score;
     DevBuf misc;
 };
+
+namespace innr {
+constexpr size_t kPinIn = 512 << 10, kPinOut = 768 << 10, kPinSmall = 256 << 10;
+
+// host -> device; small buffers go through the pinned staging area (valid until the next ctx_sync)
+static hipError_t copy_in(innr_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->pin && bytes <= kPinSmall && c->pin_in_off + bytes <= kPinIn) {
+        char* st = c->pin + c->pin_in_off;
+        memcpy(st, src, bytes);
+        c->pin_in_off += (bytes + 255) & ~(size_t)255;
+        return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, c->stream);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+}
+
+// device -> host; small buffers land in pinned memory and reach `dst` at the next ctx_sync
+static hipError_t copy_out(innr_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->pin && bytes <= kPinSmall && c->pin_out_off + bytes <= kPinOut) {
+        char* st = c->pin + kPinIn + c->pin_out_off;
+        c->pin_out_off += (bytes + 255) & ~(size_t)255;
+        c->pending.push_back({dst, st, bytes});
+        return hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+}
+
+// stream synchronise + deliver the staged outputs + recycle the staging area
+static hipError_t ctx_sync(innr_ctx* c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        for (const auto& po : c->pending) memcpy(po.user, po.staged, po.bytes);
+    c->pending.clear();
+    c->pin_in_off = c->pin_out_off = 0;
+    return e;
+}
+}  // namespace innr
+
 
 struct innr_batch {
     innr_ctx* ctx = nullptr;
@@ -150,8 +199,8 @@ static innr_status ensure_norms(innr_batch* b) {
                                                    b->max_norm_bits);
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t bits = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&bits, b->max_norm_bits, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    INNR_HIP_CHECK(copy_out(ctx, &bits, b->max_norm_bits, sizeof(bits)));
+    INNR_HIP_CHECK(ctx_sync(ctx));
     memcpy(&b->max_norm, &bits, 4);
     b->norms_ready = true;
     return INNR_OK;
@@ -461,8 +510,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     INNR_HIP_CHECK(hipGetLastError());
 
     std::vector<uint32_t> fb(Q);
-    INNR_HIP_CHECK(hipMemcpyAsync(fb.data(), fallback, Q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, fb.data(), fallback, Q * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
     uint32_t nf = 0;
@@ -478,8 +527,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
 
 static innr_status check_errflag(innr_ctx* c) {
     uint32_t e = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&e, c->flags.p, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
+    INNR_HIP_CHECK(ctx_sync(c));
     if (e) {
         set_error("internal: candidate-list invariant violated (flag=%u)", e);
         return INNR_E_HIP;
@@ -526,6 +575,7 @@ innr_status innr_ctx_create(int device, innr_ctx** out) {
     }
     c->own_stream = true;
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    if (hipHostMalloc((void**)&c->pin, kPinIn + kPinOut, hipHostMallocDefault) != hipSuccess) c->pin = nullptr;  // optional
     innr_status s = c->flags.ensure(4096);
     if (s != INNR_OK) {
         innr_ctx_destroy(c);
@@ -539,11 +589,12 @@ innr_status innr_ctx_create(int device, innr_ctx** out) {
 void innr_ctx_destroy(innr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc};
     for (DevBuf* b : bufs) b->release();
+    if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -553,7 +604,7 @@ void innr_ctx_destroy(innr_ctx* c) {
 innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
     if (!c) return INNR_E_BAD_ARG;
     INNR_TRY(bind_device(c));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(ctx_sync(c));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream (what torch uses unless told otherwise)
     c->own_stream = false;
@@ -563,7 +614,7 @@ innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
 innr_status innr_ctx_synchronize(innr_ctx* c) {
     if (!c) return INNR_E_BAD_ARG;
     INNR_TRY(bind_device(c));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -578,7 +629,7 @@ innr_status innr_batch_upload_colmajor(innr_ctx* ctx, const float* data, size_t 
     if (N && D) {
         hipError_t e = hipMemcpy2DAsync(b->V, b->ldN * sizeof(float), data, N * sizeof(float), N * sizeof(float), D,
                                         hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
         if (e != hipSuccess) {
             set_error("corpus upload failed: %s", hipGetErrorString(e));
             innr_batch_free(b);
@@ -609,12 +660,12 @@ innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t 
         }
         for (size_t i0 = 0; i0 < N && e == hipSuccess; i0 += blk) {
             const size_t n = std::min(blk, N - i0);
-            e = hipMemcpyAsync(stage, rows + i0 * D, n * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+            e = copy_in(ctx, stage, rows + i0 * D, n * D * sizeof(float));
             if (e != hipSuccess) break;
             dim3 grid((unsigned)((n + 31) / 32), (unsigned)((D + 31) / 32));
             transpose_rows_kernel<<<grid, 256, 0, ctx->stream>>>(stage, (uint32_t)n, (uint32_t)D, b->V, b->ldN, i0);
             e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = ctx_sync(ctx);
         }
         (void)hipFree(stage);
         if (e != hipSuccess) {
@@ -647,7 +698,7 @@ innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator
         else
             generate_pdx_kernel<0><<<grid, 256, 0, ctx->stream>>>(b->V, b->ldN, (uint32_t)N, (uint32_t)D, seed, row0);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
         if (e != hipSuccess) {
             set_error("generate failed: %s", hipGetErrorString(e));
             innr_batch_free(b);
@@ -662,7 +713,7 @@ void innr_batch_free(innr_batch* b) {
     if (!b) return;
     if (b->ctx) {
         (void)hipSetDevice(b->ctx->device);
-        (void)hipStreamSynchronize(b->ctx->stream);
+        (void)ctx_sync(b->ctx);
     }
     if (b->V) (void)hipFree(b->V);
     if (b->C8) (void)hipFree(b->C8);
@@ -701,7 +752,7 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     INNR_TRY(ensure_norms(b));
     if (cos) INNR_TRY(ensure_invnorms(b));
     INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
-    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
     INNR_TRY(prep_queries(b, p, c->q_row.as<float>(), Q, cos));
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
@@ -711,7 +762,7 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     else INNR_TRY((launch_gemm<kGemmDot, 1>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float),
                                     b->N * sizeof(float), Q, hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -775,8 +826,8 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
 #undef INNR_RERANK
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t hbad = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, &hbad, bad, 4));
+    INNR_HIP_CHECK(ctx_sync(c));
     if (hbad) {
         set_error("rerank: a candidate index lies outside this batch's range [%llu, %llu)",
                   (unsigned long long)b->index_base, (unsigned long long)(b->index_base + b->N));
@@ -799,13 +850,13 @@ innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, s
     INNR_TRY(c->out_idx.ensure(Q * (kout + kc) * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
     uint64_t* d_cand = c->out_idx.as<uint64_t>() + Q * kout;
-    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    INNR_HIP_CHECK(hipMemcpyAsync(d_cand, cand, Q * kc * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
+    INNR_HIP_CHECK(copy_in(c, d_cand, cand, Q * kc * sizeof(uint64_t)));
     INNR_TRY(innr_batch_rerank_dev(b, metric, c->q_row.as<float>(), Q, D, d_cand, kc, k, c->out_idx.as<uint64_t>(),
                                    c->out_score.as<float>(), out_k));
-    INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t)));
+    INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * kout * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -822,7 +873,7 @@ innr_status innr_batch_download_colmajor(innr_batch* b, float* out) {
     INNR_TRY(bind_device(b->ctx));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), b->V, b->ldN * sizeof(float), b->N * sizeof(float),
                                     b->D, hipMemcpyDeviceToHost, b->ctx->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    INNR_HIP_CHECK(ctx_sync(b->ctx));
     return INNR_OK;
 }
 
@@ -842,8 +893,8 @@ innr_status innr_batch_norms(innr_batch* b, float* out) {
     if (b->N == 0) return INNR_OK;
     INNR_TRY(bind_device(b->ctx));
     INNR_TRY(ensure_norms(b));
-    INNR_HIP_CHECK(hipMemcpyAsync(out, b->norms, b->N * sizeof(float), hipMemcpyDeviceToHost, b->ctx->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    INNR_HIP_CHECK(copy_out(b->ctx, out, b->norms, b->N * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(b->ctx));
     return INNR_OK;
 }
 
@@ -868,13 +919,13 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
     INNR_TRY(c->q_norm.ensure(sizeof(float)));
     INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, q, D * sizeof(float)));
     const float* dn = nullptr;
     if (metric == INNR_METRIC_COSINE) {
         if (norms) {  // the reference signature passes the caller's norms (batch.rs:690)
             INNR_TRY(c->tmp_norms.ensure(b->ldN * sizeof(float)));
             INNR_HIP_CHECK(hipMemsetAsync(c->tmp_norms.p, 0, b->ldN * sizeof(float), c->stream));
-            INNR_HIP_CHECK(hipMemcpyAsync(c->tmp_norms.p, norms, b->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            INNR_HIP_CHECK(copy_in(c, c->tmp_norms.p, norms, b->N * sizeof(float)));
             dn = c->tmp_norms.as<float>();
         } else {
             INNR_TRY(ensure_norms(b));
@@ -902,8 +953,8 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
             break;
     }
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_HIP_CHECK(hipMemcpyAsync(out, ds, b->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, out, ds, b->N * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -991,13 +1042,13 @@ innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size
     INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
     INNR_TRY(innr_batch_knn_dev(b, metric, c->q_row.as<float>(), Q, D, k, engine, c->out_idx.as<uint64_t>(),
                                 c->out_score.as<float>(), out_k, stats));
     if (*out_k) {
-        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * kout * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
     }
     return INNR_OK;
 }
@@ -1044,12 +1095,12 @@ innr_status innr_batch_upload_u8(innr_ctx* ctx, const uint8_t* codes, size_t N, 
         hipError_t e = hipMalloc((void**)&stage, blk * D);
         for (size_t i0 = 0; i0 < N && e == hipSuccess; i0 += blk) {
             const size_t n = std::min(blk, N - i0);
-            e = hipMemcpyAsync(stage, codes + i0 * D, n * D, hipMemcpyHostToDevice, ctx->stream);
+            e = copy_in(ctx, stage, codes + i0 * D, n * D);
             if (e != hipSuccess) break;
             dim3 grid((unsigned)((n + 31) / 32), (unsigned)((D + 31) / 32));
             transpose_rows_u8_kernel<<<grid, 256, 0, ctx->stream>>>(stage, (uint32_t)n, (uint32_t)D, b->C8, b->ldN, i0);
             e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = ctx_sync(ctx);
         }
         if (stage) (void)hipFree(stage);
         if (e != hipSuccess) {
@@ -1071,7 +1122,7 @@ innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t s
         generate_u8_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(b->C8, b->ldN, (uint32_t)N, (uint32_t)D, seed, row0, offset,
                                                               255.0f / alpha);  // scalar.rs:213 inv_alpha
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
         if (e != hipSuccess) {
             set_error("u8 generate failed: %s", hipGetErrorString(e));
             innr_batch_free(b);
@@ -1097,7 +1148,7 @@ innr_status innr_batch_quantize_u8(innr_batch* src, float alpha, float offset, i
         quantize_pdx_kernel<<<grid, 256, 0, ctx->stream>>>(src->V, src->ldN, (uint32_t)src->N, (uint32_t)src->D, offset,
                                                            255.0f / alpha, b->C8, b->ldN);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
         if (e != hipSuccess) {
             set_error("device quantize failed: %s", hipGetErrorString(e));
             innr_batch_free(b);
@@ -1126,8 +1177,8 @@ innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int
     minmax_pdx_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, c->misc.as<uint32_t>());
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t k[2] = {0, 0};
-    INNR_HIP_CHECK(hipMemcpyAsync(k, c->misc.p, 8, hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, k, c->misc.p, 8));
+    INNR_HIP_CHECK(ctx_sync(c));
     if (k[0] && k[1]) {  // at least one non-NaN value
         *out_any = 1;
         *out_min = ord_f32(~k[0]);
@@ -1141,7 +1192,7 @@ innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out) {
     if (b->N == 0 || b->D == 0) return INNR_OK;
     INNR_TRY(bind_device(b->ctx));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N, b->C8, b->ldN, b->N, b->D, hipMemcpyDeviceToHost, b->ctx->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    INNR_HIP_CHECK(ctx_sync(b->ctx));
     return INNR_OK;
 }
 
@@ -1168,7 +1219,7 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
     INNR_TRY(c->q_norm.ensure(2 * sizeof(float)));
     INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, q, D * sizeof(float)));
     float* qsum = c->q_norm.as<float>();
     query_sums_kernel<<<1, 64, 0, c->stream>>>(c->q_row.as<float>(), 1, (uint32_t)D, ldq, qsum, qsum + 1);
     const size_t nchunks = b->ldN / kU8Chunk;
@@ -1176,8 +1227,8 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
     scan_u8_scores_kernel<1><<<blocks, 256, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)D, c->q_row.as<float>(), ldq, qsum,
                                                             b->alpha / 255.0f, b->offset, c->scores.as<float>(), b->ldN);
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_HIP_CHECK(hipMemcpyAsync(out, c->scores.p, b->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, out, c->scores.p, b->N * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -1270,8 +1321,8 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
 #undef INNR_RESCORE_U8
     INNR_HIP_CHECK(hipGetLastError());
     std::vector<uint32_t> fb(Q);
-    INNR_HIP_CHECK(hipMemcpyAsync(fb.data(), fallback, Q * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, fb.data(), fallback, Q * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
     uint32_t nf = 0;
@@ -1345,13 +1396,13 @@ innr_status innr_batch_knn_u8(innr_batch* b, const float* queries, size_t Q, siz
     INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, queries, Q * D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
     INNR_TRY(innr_batch_knn_u8_dev(b, c->q_row.as<float>(), Q, D, k, engine, c->out_idx.as<uint64_t>(),
                                    c->out_score.as<float>(), out_k, stats));
     if (*out_k) {
-        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, Q * kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, Q * kout * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * kout * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
     }
     return INNR_OK;
 }
@@ -1419,7 +1470,7 @@ innr_status innr_maxsim_generate(innr_ctx* ctx, size_t ndocs, size_t T, size_t d
     if (ntok && dim) {
         generate_tokens_kernel<<<(unsigned)((ntok + 255) / 256), 256, 0, ctx->stream>>>(d->tok, ntok, (uint32_t)dim, seed, row0);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
         if (e != hipSuccess) {
             set_error("maxsim generate failed: %s", hipGetErrorString(e));
             innr_docs_free(d);
@@ -1434,7 +1485,7 @@ void innr_docs_free(innr_docs* d) {
     if (!d) return;
     if (d->ctx) {
         (void)hipSetDevice(d->ctx->device);
-        (void)hipStreamSynchronize(d->ctx->stream);
+        (void)ctx_sync(d->ctx);
     }
     if (d->tok) (void)hipFree(d->tok);
     if (d->doc_len) (void)hipFree(d->doc_len);
@@ -1457,7 +1508,7 @@ static innr_status maxsim_stage_query(innr_docs* d, int cosine, const float* qto
     INNR_TRY(c->q_row.ensure(Tq_pad * dim * sizeof(float)));
     INNR_TRY(c->q_norm.ensure(2 * Tq_pad * sizeof(float)));  // [Tq_pad] squared norms, [Tq_pad] 1/norm (MFMA engine)
     INNR_HIP_CHECK(hipMemsetAsync(c->q_row.p, 0, Tq_pad * dim * sizeof(float), c->stream));
-    INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, qtok, Tq * dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(copy_in(c, c->q_row.p, qtok, Tq * dim * sizeof(float)));
     if (cosine) {
         query_token_sq_kernel<<<(unsigned)((Tq_pad + 63) / 64), 64, 0, c->stream>>>(c->q_row.as<float>(), (uint32_t)Tq_pad,
                                                                                    (uint32_t)dim, c->q_norm.as<float>());
@@ -1528,8 +1579,8 @@ innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size
     INNR_TRY(bind_device(d->ctx));
     INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
     if (d->ndocs) {
-        INNR_HIP_CHECK(hipMemcpyAsync(out, d->ctx->scores.p, d->ndocs * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+        INNR_HIP_CHECK(copy_out(d->ctx, out, d->ctx->scores.p, d->ndocs * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(d->ctx));
     }
     return INNR_OK;
 }
@@ -1575,8 +1626,8 @@ static innr_status maxsim_ensure_token_norms(innr_docs* d) {
                                                                                      c->misc.as<uint32_t>());
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t bits = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&bits, c->misc.p, 4, hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, &bits, c->misc.p, 4));
+    INNR_HIP_CHECK(ctx_sync(c));
     memcpy(&d->max_norm, &bits, 4);
     return INNR_OK;
 }
@@ -1675,8 +1726,8 @@ static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok,
                                                    c->out_score.as<float>(), flag);
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t ok = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&ok, flag, 4, hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, &ok, flag, 4));
+    INNR_HIP_CHECK(ctx_sync(c));
     *proven = ok != 0;
     return INNR_OK;
 }
@@ -1735,9 +1786,9 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     }
     INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     INNR_TRY(check_errflag(c));
-    INNR_HIP_CHECK(hipMemcpyAsync(out_doc, c->out_idx.p, kout * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, kout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, out_doc, c->out_idx.p, kout * sizeof(uint64_t)));
+    INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, kout * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
     *out_k = kout;
     if (stats) {
         stats->engine = used;
@@ -1769,8 +1820,8 @@ innr_status innr_batch_dimension_variance(innr_batch* b, float* out) {
                                                                                     (uint32_t)b->D, c->misc.as<float>());
         INNR_HIP_CHECK(hipGetLastError());
         b->dimvar.resize(b->D);
-        INNR_HIP_CHECK(hipMemcpyAsync(b->dimvar.data(), c->misc.p, b->D * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        INNR_HIP_CHECK(copy_out(c, b->dimvar.data(), c->misc.p, b->D * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
     }
     memcpy(out, b->dimvar.data(), b->D * sizeof(float));
     return INNR_OK;
@@ -1801,29 +1852,29 @@ static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k,
     INNR_TRY(c->q_row.ensure(std::max<size_t>(D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, q, D * sizeof(float)));
     ScanExt ext;
     if (mask) {
         INNR_TRY(c->tmp_norms.ensure(b->ldN));  // reused as the predicate byte array, zero padded
         INNR_HIP_CHECK(hipMemsetAsync(c->tmp_norms.p, 0, b->ldN, c->stream));
-        INNR_HIP_CHECK(hipMemcpyAsync(c->tmp_norms.p, mask, b->N, hipMemcpyHostToDevice, c->stream));
+        INNR_HIP_CHECK(copy_in(c, c->tmp_norms.p, mask, b->N));
         ext.mask = c->tmp_norms.as<uint8_t>();
     }
     if (order_host) {
         INNR_TRY(c->misc.ensure(std::max<size_t>(D, 1) * sizeof(uint32_t)));
-        INNR_HIP_CHECK(hipMemcpyAsync(c->misc.p, order_host, D * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        INNR_HIP_CHECK(copy_in(c, c->misc.p, order_host, D * sizeof(uint32_t)));
         ext.order = c->misc.as<uint32_t>();
     }
     INNR_TRY(knn_exact_range(b, INNR_METRIC_L2SQ, c->q_row.as<float>(), D, nullptr, 0, 1, kout, c->out_idx.as<uint64_t>(),
                              c->out_score.as<float>(), ext));
     uint32_t have = 0;  // filtered: fewer than k vectors may pass (k = k.min(num_passing), batch.rs:849)
-    INNR_HIP_CHECK(hipMemcpyAsync(&have, c->sel_cnt.p, sizeof(have), hipMemcpyDeviceToHost, c->stream));
+    INNR_HIP_CHECK(copy_out(c, &have, c->sel_cnt.p, sizeof(have)));
     INNR_TRY(check_errflag(c));
     const size_t n = std::min<size_t>(kout, have);
     if (n) {
-        INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipMemcpyAsync(out_score, c->out_score.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, n * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, n * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
     }
     *out_k = n;
     return INNR_OK;
@@ -1872,7 +1923,7 @@ innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t 
     const size_t ldq = round_up(D ? D : 1, 4);
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
     INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
-    if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_row.p, q, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, q, D * sizeof(float)));
     const size_t nchunks = b->ldN / kScanChunk;
     const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
     scan_scores_kernel<1, true, false><<<blocks, kScanThreads, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, c->q_row.as<float>(),
@@ -1888,8 +1939,8 @@ innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t 
     exclusive_scan_kernel<<<1, 1024, 0, c->stream>>>(cnt, nb, off, total);
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t n = 0;
-    INNR_HIP_CHECK(hipMemcpyAsync(&n, total, sizeof(n), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, &n, total, sizeof(n)));
+    INNR_HIP_CHECK(ctx_sync(c));
     *out_n = n;  // survivors found; the caller's buffers hold min(n, cap) of them
     const size_t m = std::min<size_t>(n, cap);
     if (m == 0) return INNR_OK;
@@ -1899,9 +1950,9 @@ innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t 
     prune_scatter_kernel<<<nb, 256, 0, c->stream>>>(c->scores.as<float>(), (uint32_t)b->N, threshold, off, b->index_base,
                                                    c->out_idx.as<uint64_t>(), c->out_score.as<float>(), (uint32_t)m);
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_HIP_CHECK(hipMemcpyAsync(out_idx, c->out_idx.p, m * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipMemcpyAsync(out_dist, c->out_score.p, m * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+    INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, m * sizeof(uint64_t)));
+    INNR_HIP_CHECK(copy_out(c, out_dist, c->out_score.p, m * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
 
@@ -1918,7 +1969,7 @@ innr_status innr_merge_topk_dev(innr_ctx* ctx, int metric, const uint64_t* d_idx
                                                           (uint32_t)kout, metric == INNR_METRIC_L2SQ, d_out_idx,
                                                           d_out_score);
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    INNR_HIP_CHECK(ctx_sync(ctx));
     return INNR_OK;
 }
 

@@ -60,7 +60,7 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
     # the only parallelism a reference user could add without changing innr: one query per host core
     try:
         from concurrent.futures import ThreadPoolExecutor
-        cores = len(os.sched_getaffinity(0))
+        cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box's CPU share is 16 cores whatever the affinity mask says
         if cores > 1:
             def one(j):
                 oracle.batch_knn_dot(queries[j % len(queries)], data, k)  # ctypes releases the GIL

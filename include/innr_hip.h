@@ -200,6 +200,9 @@ float innr_dot_f32(const float* a, const float* b, size_t n);    /* dense::dot_p
 float innr_cosine_f32(const float* a, const float* b, size_t n); /* dense::cosine_portable dense.rs:288; DistCosine = 1 - cosine, distance.rs:76 */
 float innr_l2sq_f32(const float* a, const float* b, size_t n);   /* dense::l2_distance_squared_portable dense.rs:648; DistL2 = sqrt, distance.rs:99 */
 float innr_l1_f32(const float* a, const float* b, size_t n);     /* dense::l1_distance_portable dense.rs:550; DistL1, distance.rs:110 */
+/* DistHamming (u8 bit-Hamming, distance.rs:116-126) and DistSlotU32 (fraction of differing u32 slots, :128-143) */
+uint32_t innr_hamming_u8(const uint8_t* a, const uint8_t* b, size_t n);
+float innr_slot_distance_u32(const uint32_t* a, const uint32_t* b, size_t n);
 /* maxsim / maxsim_cosine of ONE (query, document) pair (maxsim.rs:96-194, portable path :142-152); tokens packed
  * row-major [n][dim]; cosine != 0 selects maxsim_cosine. Empty query or document -> 0.0. */
 innr_status innr_maxsim_pair(const float* q, size_t nq, const float* d, size_t nd, size_t dim, int cosine, float* out);

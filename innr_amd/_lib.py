@@ -110,6 +110,8 @@ SIGNATURES = {
     "innr_cosine_f32": (C.c_float, [_vp, _vp, _sz]),
     "innr_l2sq_f32": (C.c_float, [_vp, _vp, _sz]),
     "innr_l1_f32": (C.c_float, [_vp, _vp, _sz]),
+    "innr_hamming_u8": (C.c_uint32, [_vp, _vp, _sz]),
+    "innr_slot_distance_u32": (C.c_float, [_vp, _vp, _sz]),
     "innr_maxsim_pair": (C.c_int, [_vp, _sz, _vp, _sz, _sz, C.c_int, _f32p]),
 }
 

@@ -88,6 +88,21 @@ float innr_cosine_f32(const float* a, const float* b, size_t n) { return cosine_
 float innr_l2sq_f32(const float* a, const float* b, size_t n) { return l2sq_portable(a, b, n); }
 float innr_l1_f32(const float* a, const float* b, size_t n) { return l1_portable(a, b, n); }
 
+// DistHamming over byte-packed binary vectors (distance.rs:116-126 -> quant.rs hamming_portable: XOR, count bits) and
+// DistSlotU32, the fraction of differing u32 slots (distance.rs:128-143 -> slot.rs:392-405; empty -> 0.0). Integer
+// work: exact by construction, any order.
+uint32_t innr_hamming_u8(const uint8_t* a, const uint8_t* b, size_t n) {
+    uint32_t bits = 0;
+    for (size_t i = 0; i < n; ++i) bits += (uint32_t)__builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return bits;
+}
+float innr_slot_distance_u32(const uint32_t* a, const uint32_t* b, size_t n) {
+    if (n == 0) return 0.0f;
+    uint32_t diff = 0;
+    for (size_t i = 0; i < n; ++i) diff += a[i] != b[i];
+    return (float)diff / (float)n;
+}
+
 // quantize_u8 (scalar.rs:212-225): one-time ingest on the host; f32::round = half away from zero = roundf,
 // `as u8` saturates and maps NaN to 0.
 void innr_quantize_u8(const float* values, size_t n, float alpha, float offset, uint8_t* out) {

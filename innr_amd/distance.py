@@ -54,3 +54,31 @@ class DistL2(Distance):
 class DistL1(Distance):
     """distance.rs:107-114: Manhattan distance."""
     def eval(self, a, b) -> float: return l1_distance(a, b)
+
+
+def hamming_distance(a, b) -> int:
+    """quant.rs:220-258: differing bits between two byte-packed binary vectors; panics on a length mismatch."""
+    x = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    y = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+    if x.size != y.size:
+        raise InnrPanic(f"innr::hamming_distance: slice length mismatch ({x.size} vs {y.size})")
+    return int(load().innr_hamming_u8(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), x.size))
+
+
+def jaccard_distance(a, b) -> float:
+    """slot.rs:392-405: fraction of differing u32 slots (0.0 for empty inputs); panics on a length mismatch."""
+    x = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1)
+    y = np.ascontiguousarray(b, dtype=np.uint32).reshape(-1)
+    if x.size != y.size:
+        raise InnrPanic(f"innr::jaccard_distance: slice length mismatch ({x.size} vs {y.size})")
+    return float(load().innr_slot_distance_u32(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), x.size))
+
+
+class DistHamming(Distance):
+    """distance.rs:116-126"""
+    def eval(self, a, b) -> float: return float(hamming_distance(a, b))
+
+
+class DistSlotU32(Distance):
+    """distance.rs:128-143"""
+    def eval(self, a, b) -> float: return jaccard_distance(a, b)

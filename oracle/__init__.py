@@ -264,6 +264,22 @@ def dist_l2(a, b): return _pair(lib().orc_dist_l2)(a, b)
 def dist_l1(a, b): return _pair(lib().orc_dist_l1)(a, b)
 
 
+def dist_hamming(a, b) -> float:
+    x = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1); y = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+    assert x.size == y.size
+    f = lib().orc_dist_hamming
+    f.restype, f.argtypes = C.c_float, [C.c_void_p, C.c_void_p, C.c_size_t]
+    return float(f(x.ctypes.data, y.ctypes.data, x.size))
+
+
+def dist_slot_u32(a, b) -> float:
+    x = np.ascontiguousarray(a, dtype=np.uint32).reshape(-1); y = np.ascontiguousarray(b, dtype=np.uint32).reshape(-1)
+    assert x.size == y.size
+    f = lib().orc_dist_slot_u32
+    f.restype, f.argtypes = C.c_float, [C.c_void_p, C.c_void_p, C.c_size_t]
+    return float(f(x.ctypes.data, y.ctypes.data, x.size))
+
+
 def _tok(t):
     t = _f(t)
     if t.size == 0:

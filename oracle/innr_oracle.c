@@ -595,6 +595,25 @@ float orc_dist_dot(const float* a, const float* b, size_t n) { return -orc_dot_p
 float orc_dist_l2(const float* a, const float* b, size_t n) { return sqrtf(orc_l2_distance_squared_portable(a, b, n)); }
 float orc_dist_l1(const float* a, const float* b, size_t n) { return orc_l1_distance_portable(a, b, n); }
 
+/* distance.rs:116-126 (DistHamming -> quant.rs hamming_portable: XOR, count bits) and :128-143 (DistSlotU32 -> slot.rs:392-405) */
+float orc_dist_hamming(const uint8_t* a, const uint8_t* b, size_t n) {
+    uint32_t bits = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t x = (uint8_t)(a[i] ^ b[i]);
+        while (x) {
+            bits += x & 1u;
+            x >>= 1;
+        }
+    }
+    return (float)bits;
+}
+float orc_dist_slot_u32(const uint32_t* a, const uint32_t* b, size_t n) {
+    if (n == 0) return 0.0f;
+    uint32_t diff = 0;
+    for (size_t i = 0; i < n; ++i) diff += (a[i] != b[i]) ? 1u : 0u;
+    return (float)diff / (float)n;
+}
+
 /* ------------------------------------------------------------------------------------------
  * maxsim (portable path maxsim.rs:142-152; cosine variant :168-194)
  * f32::max ignores a NaN operand (returns the other) == C fmaxf.

@@ -81,6 +81,8 @@ float orc_dist_cosine(const float* a, const float* b, size_t n); /* 1 - cosine *
 float orc_dist_dot(const float* a, const float* b, size_t n);    /* -dot */
 float orc_dist_l2(const float* a, const float* b, size_t n);     /* sqrt(l2sq) */
 float orc_dist_l1(const float* a, const float* b, size_t n);
+float orc_dist_hamming(const uint8_t* a, const uint8_t* b, size_t n);      /* distance.rs:116-126 */
+float orc_dist_slot_u32(const uint32_t* a, const uint32_t* b, size_t n);  /* distance.rs:128-143 */
 
 /* ---- maxsim (maxsim.rs:96-194, portable path :142-152). Tokens packed row-major [n_tok][dim]. */
 float orc_maxsim(const float* q, size_t nq, const float* d, size_t nd, size_t dim);

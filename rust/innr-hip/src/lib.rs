@@ -72,6 +72,8 @@ pub mod ffi {
         pub fn innr_cosine_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_l2sq_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_l1_f32(a: *const f32, b: *const f32, n: usize) -> f32;
+        pub fn innr_hamming_u8(a: *const u8, b: *const u8, n: usize) -> u32;
+        pub fn innr_slot_distance_u32(a: *const u32, b: *const u32, n: usize) -> f32;
     }
 }
 
@@ -397,4 +399,12 @@ pub mod distance {
     impl Distance<f32> for DistDot { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { -pair(ffi::innr_dot_f32, a, b) } }            // :85-92
     impl Distance<f32> for DistL2 { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { pair(ffi::innr_l2sq_f32, a, b).sqrt() } }      // :96-103
     impl Distance<f32> for DistL1 { fn eval(&self, a: &[f32], b: &[f32]) -> f32 { pair(ffi::innr_l1_f32, a, b) } }                // :107-114
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistHamming;
+    #[derive(Default, Clone, Copy, Debug)] pub struct DistSlotU32;
+    impl Distance<u8> for DistHamming {                                                                                          // :116-126
+        fn eval(&self, a: &[u8], b: &[u8]) -> f32 { assert_eq!(a.len(), b.len()); unsafe { ffi::innr_hamming_u8(a.as_ptr(), b.as_ptr(), a.len()) as f32 } }
+    }
+    impl Distance<u32> for DistSlotU32 {                                                                                         // :128-143
+        fn eval(&self, a: &[u32], b: &[u32]) -> f32 { assert_eq!(a.len(), b.len()); unsafe { ffi::innr_slot_distance_u32(a.as_ptr(), b.as_ptr(), a.len()) } }
+    }
 }

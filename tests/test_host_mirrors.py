@@ -47,6 +47,10 @@ def test_pairwise_bit_exact_vs_oracle(mods):
         assert D.DistDot().eval(a, b) == oracle.dist_dot(a, b)
         assert D.DistL2().eval(a, b) == oracle.dist_l2(a, b)
         assert D.DistL1().eval(a, b) == oracle.dist_l1(a, b)
+        ua, ub = rng.integers(0, 256, n, dtype=np.uint8), rng.integers(0, 256, n, dtype=np.uint8)
+        assert D.DistHamming().eval(ua, ub) == oracle.dist_hamming(ua, ub) == float(np.unpackbits(ua ^ ub).sum())
+        sa, sb = rng.integers(0, 3, n, dtype=np.uint32), rng.integers(0, 3, n, dtype=np.uint32)
+        assert D.DistSlotU32().eval(sa, sb) == oracle.dist_slot_u32(sa, sb)
     for nq, nd, dim in ((1, 1, 1), (5, 9, 33), (32, 64, 128), (3, 2, 7)):
         q = rng.normal(size=(nq, dim)).astype(np.float32)
         d = rng.normal(size=(nd, dim)).astype(np.float32)
@@ -57,6 +61,11 @@ def test_pairwise_bit_exact_vs_oracle(mods):
 def test_pairwise_panics_and_guards(mods):
     D, M, _ = mods
     from innr_amd import InnrPanic
+    with pytest.raises(InnrPanic):
+        D.hamming_distance([1, 2], [1])          # quant.rs:221-227
+    with pytest.raises(InnrPanic):
+        D.jaccard_distance([1, 2, 3], [1, 2])    # slot.rs:393-399
+    assert D.jaccard_distance([], []) == 0.0     # slot.rs:401-403
     with pytest.raises(InnrPanic):
         D.dot([1.0, 2.0], [1.0])  # dense.rs:57-63
     with pytest.raises(InnrPanic):

@@ -238,6 +238,14 @@ def test_distance_trait_metrics():  # src/distance.rs:195-264 shapes
     assert abs(oracle.dist_l2([0, 0], [3, 4]) - 5.0) < 1e-6
     assert oracle.dist_l1([0, 0], [3, -4]) == 7.0
     assert oracle.cosine_portable([1, 0], [0, 0]) == 0.0  # zero vector guard (dense.rs:341-345)
+    # integer metrics (distance.rs:230-243, quant.rs doc example, slot.rs:385-388)
+    assert oracle.dist_hamming([0b11110000], [0b10101010]) == 4.0
+    assert oracle.dist_hamming([0b11110000, 0xFF], [0b10101010, 0x00]) == 12.0
+    assert oracle.dist_slot_u32([1, 2, 3, 4], [1, 0, 3, 9]) == 0.5
+    assert oracle.dist_slot_u32([1, 2, 3, 4], [1, 2, 3, 9]) == 0.25
+    assert oracle.dist_slot_u32([], []) == 0.0
+    sketches = [[1, 2, 3, 4], [1, 2, 3, 9], [9, 9, 9, 9]]  # generic_index_over_metric, distance.rs:260-262
+    assert min(range(3), key=lambda i: oracle.dist_slot_u32([1, 2, 3, 4], sketches[i])) == 0
 
 
 # ------------------------------------------------------------------ example-level checks

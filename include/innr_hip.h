@@ -92,6 +92,8 @@ innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t 
 innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator, uint64_t seed, uint64_t row0,
                                 innr_batch** out);
 void innr_batch_free(innr_batch* b);
+/* introspection (cf. backend.rs:40-67): the engine INNR_KNN_AUTO resolves to for a Q-query call on this batch */
+int innr_batch_auto_engine(const innr_batch* b, size_t Q);
 size_t innr_batch_num_vectors(const innr_batch* b); /* batch.rs:199 */
 size_t innr_batch_dimension(const innr_batch* b);   /* batch.rs:204 */
 /* copy the dimension-major data back (VerticalBatch::data(), batch.rs:212): out[D*N] */

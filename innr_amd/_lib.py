@@ -74,6 +74,7 @@ SIGNATURES = {
     "innr_batch_upload_rowmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
     "innr_batch_generate": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(_vp)]),
     "innr_batch_free": (None, [_vp]),
+    "innr_batch_auto_engine": (C.c_int, [_vp, _sz]),
     "innr_batch_num_vectors": (_sz, [_vp]),
     "innr_batch_dimension": (_sz, [_vp]),
     "innr_batch_download_colmajor": (C.c_int, [_vp, _vp]),

@@ -860,6 +860,12 @@ innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, s
     return INNR_OK;
 }
 
+// which engine INNR_KNN_AUTO resolves to for a Q-query call on this batch (introspection, cf. backend.rs:40-67)
+int innr_batch_auto_engine(const innr_batch* b, size_t Q) {
+    if (!b) return INNR_KNN_EXACT;
+    return (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+}
+
 size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
 size_t innr_batch_dimension(const innr_batch* b) { return b ? b->D : 0; }
 
@@ -987,7 +993,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     INNR_TRY(bind_device(c));
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
-    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     const float* dQn = nullptr;
@@ -1359,7 +1365,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     float* qnorm = qsum + round_up(Q, kBQ);
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
-    if (engine == INNR_KNN_AUTO) engine = (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
     uint32_t nfallback = 0, kept = pick_kp(kout, 0);
     float gemm_ms = 0.0f;
     if (engine == INNR_KNN_MFMA) {

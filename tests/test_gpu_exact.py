@@ -267,3 +267,13 @@ def test_index_base_offsets_reported_indices(B, innr):
     r = B.batch_knn_dot(q, vb, 4)
     oi, _ = oracle.batch_knn_dot(q, data, 4)
     assert r.indices == [int(i) + (1 << 33) for i in oi]
+
+
+def test_backend_introspection(B, innr):
+    from innr_amd import backend as BK
+    small, big = B.VerticalBatch.generate(3000, 16, 0), B.VerticalBatch.generate(70_000, 16, 0)
+    assert BK.batch_backend(small, 100) == BK.Backend.HIP_EXACT and BK.batch_backend(big, 1) == BK.Backend.HIP_EXACT
+    assert BK.batch_backend(big, 100) == BK.Backend.HIP_MFMA and str(BK.dense_backend(768)) == "portable"
+    st = innr.KnnStats()
+    B.batch_knn_dot_multi(oracle.generate_uniform(100, 16, 1), big, 3, stats=st)
+    assert st.engine == innr.KNN_MFMA and "gfx950" in BK.version()

@@ -15,6 +15,7 @@ Every computation runs on the GPU through include/innr_hip.h; nothing here compu
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
@@ -95,6 +96,36 @@ class VerticalBatch:
         check(load().innr_batch_generate(ctx.handle, num_vectors, dimension, int(generator), C.c_uint64(seed),
                                          C.c_uint64(row0), C.byref(h)))
         return cls(h, num_vectors, dimension, ctx)
+
+    # ---- persistence: a minimal file around VerticalBatch::data() (batch.rs:208-214) -----------------------------
+    _MAGIC = b"INNRPDX1"  # 8-byte magic, u64 num_vectors, u64 dimension, then dimension x num_vectors f32 (data() order)
+
+    def save(self, path: str) -> None:
+        """Write the batch in its own dimension-major order. The device copy goes straight into a memory-mapped file:
+        no second host buffer, so a 30 GB shard does not need 30 GB of RAM."""
+        with open(path, "wb") as f:
+            f.write(self._MAGIC + np.array([self._n, self._d], dtype="<u8").tobytes())
+            f.truncate(24 + 4 * self._n * self._d)
+        if self._n * self._d:
+            mm = np.memmap(path, dtype="<f4", mode="r+", offset=24, shape=(self._d, self._n))
+            check(load().innr_batch_download_colmajor(self._h, _vp(mm)))
+            mm.flush()
+            del mm
+
+    @classmethod
+    def load(cls, path: str, ctx: Optional[_lib.Context] = None) -> "VerticalBatch":
+        """Inverse of save(): the file is memory-mapped and uploaded as it is (already the device's layout order)."""
+        with open(path, "rb") as f:
+            head = f.read(24)
+        if len(head) != 24 or head[:8] != cls._MAGIC:
+            raise InnrPanic(f"{path}: not an innr PDX file")
+        n, d = (int(x) for x in np.frombuffer(head[8:], dtype="<u8"))
+        if os.path.getsize(path) != 24 + 4 * n * d:
+            raise InnrPanic(f"{path}: size does not match its header ({n} x {d})")
+        if n * d == 0:
+            return cls._upload("innr_batch_upload_colmajor", np.empty(0, np.float32), n, d, ctx)
+        mm = np.memmap(path, dtype="<f4", mode="r", offset=24, shape=(d * n,))
+        return cls._upload("innr_batch_upload_colmajor", mm, n, d, ctx)
 
     # ---- accessors (batch.rs:187-219) --------------------------------------------------------------
     def num_vectors(self) -> int:

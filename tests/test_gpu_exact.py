@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -277,3 +279,24 @@ def test_backend_introspection(B, innr):
     st = innr.KnnStats()
     B.batch_knn_dot_multi(oracle.generate_uniform(100, 16, 1), big, 3, stats=st)
     assert st.engine == innr.KNN_MFMA and "gfx950" in BK.version()
+
+
+def test_save_load_roundtrip(B, tmp_path):
+    rows = oracle.generate_uniform(1234, 37, 4)
+    vb = B.VerticalBatch.from_rows(rows)
+    path = str(tmp_path / "corpus.pdx")
+    vb.save(path)
+    assert os.path.getsize(path) == 24 + 4 * 1234 * 37
+    vb2 = B.VerticalBatch.load(path)
+    assert vb2.num_vectors() == 1234 and vb2.dimension() == 37 and np.array_equal(vb2.data(), vb.data())
+    q = oracle.generate_uniform(1, 37, 9)[0]
+    assert B.batch_knn_dot(q, vb2, 5) == B.batch_knn_dot(q, vb, 5)
+    empty = B.VerticalBatch.from_rows([])
+    empty.save(path)
+    e2 = B.VerticalBatch.load(path)
+    assert e2.num_vectors() == 0 and e2.dimension() == 0
+    with open(path, "wb") as f:
+        f.write(b"not a pdx file, but long enough....")
+    import innr_amd
+    with pytest.raises(innr_amd.InnrPanic):
+        B.VerticalBatch.load(path)

@@ -216,3 +216,46 @@ def test_full_size_properties_c2(B, innr):
     i2, s2 = B.batch_knn_multi(qs[:16], vb, k, engine=innr.KNN_EXACT)
     assert np.array_equal(idx[:16], i2) and bits_equal(sc[:16], s2)
     print(f"C2 l2: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")
+
+
+@pytest.mark.parametrize("cluster", [20, 200])
+def test_knn_mfma_near_ties_around_the_cut(B, innr, cluster):
+    """Adversarial for the margin proof: `cluster` corpus vectors are copies of the query direction perturbed in the
+    last bits, so their exact scores differ by a few ulps and the MFMA (fma-chain) order among them is arbitrary.
+    cluster < KP: all of them are candidates, exact re-scoring settles the order, the proof holds. cluster > KP: the
+    cut runs through the cluster, nothing can be proven and the exact engine must take over. Either way the answer is
+    the oracle's, bit for bit."""
+    n, dim, k = 60_000, 64, 10
+    rows = oracle.generate_uniform(n, dim, 17) * np.float32(0.25)
+    qs = oracle.generate_uniform(24, dim, 18)
+    rng = np.random.default_rng(3)
+    for j in range(len(qs)):  # each query gets its own cluster, scattered over the corpus
+        pos = rng.choice(n, size=cluster, replace=False)
+        noise = (1.0 + rng.integers(-3, 4, size=(cluster, dim)) * 2.0 ** -23).astype(np.float32)
+        rows[pos] = (qs[j] * np.float32(1.5)) * noise
+    data = oracle.from_rows(rows)
+    vb = B.VerticalBatch.from_rows(rows)
+    for metric in ("dot", "cos", "l2"):
+        fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
+        ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine, "l2": oracle.batch_knn}[metric]
+        st = innr.KnnStats()
+        idx, sc = fn(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+        for j, q in enumerate(qs):
+            oi, os_ = ofn(q, data, k)
+            if metric != "l2":
+                assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, cluster, j)
+                continue
+            # batch_knn keeps k of the vectors tied at the k-th distance; WHICH of them is a property of core's
+            # binary_search inside TopK::insert (topk.rs:177-185), so at the cut only the distances are comparable:
+            # identical score lists, identical indices above the last distance value, and every index reported at the
+            # last value really lies at that distance
+            assert bits_equal(sc[j], os_), (cluster, j)
+            last = os_[-1]
+            inner = os_ != last
+            assert sorted(idx[j][inner].tolist()) == sorted(oi[inner].tolist()), (cluster, j)
+            full = oracle.batch_l2_squared(q, data)
+            assert all(full[int(i)] == last for i in idx[j][~inner]) and len(set(idx[j].tolist())) == k
+        if cluster > 32 and metric != "l2":
+            assert st.queries_fallback >= len(qs) // 2, (metric, st.queries_fallback)  # the cut is inside the cluster
+        if cluster < 32 and metric == "dot":
+            assert st.queries_fallback <= 2, st.queries_fallback

@@ -351,17 +351,21 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
 // ---- GEMM engine -------------------------------------------------------------------------------------
 struct GemmPlan {
     size_t Qpad;
-    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks;
+    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, waves;
 };
 
-static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout) {
+static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t force_waves = 0) {
     GemmPlan p;
-    p.Qpad = round_up(Q, kBQ);
-    p.nqt = (uint32_t)(p.Qpad / kBQ);
+    p.waves = Q > 256 ? 8u : 4u;  // 512-query tiles halve the corpus re-reads; <= 256 queries fit one 4-wave tile
+    if (const char* e = getenv("INNR_GEMM_WAVES")) p.waves = atoi(e) == 8 ? 8u : 4u;
+    if (force_waves) p.waves = force_waves;
+    const size_t bq = 64 * p.waves;
+    p.Qpad = round_up(Q, bq);
+    p.nqt = (uint32_t)(p.Qpad / bq);
     p.KP = pick_kp(kout, 16);
     p.cap = (uint32_t)cand_cap((int)p.KP);
     const uint32_t ntiles = (uint32_t)(b->ldN / kBC);
-    uint32_t target = (uint32_t)(2 * b->ctx->num_cus) / p.nqt;  // two resident blocks per CU
+    uint32_t target = (uint32_t)((8 / p.waves) * b->ctx->num_cus) / p.nqt;  // resident blocks per CU: 8 waves' worth
     uint32_t ns = std::max(8u, target / 8 * 8);
     ns = std::min(ns, (uint32_t)round_up(ntiles, 8));
     p.nslices = ns;
@@ -395,11 +399,17 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     INNR_TRY(c->gthr.ensure(gbytes));
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
-#define INNR_GEMM_LAUNCH(RR)                                                                                    \
-    gemm_filter_kernel<KIND, RR, MODE><<<p.nblocks, kGemmThreads, 0, c->stream>>>(                                \
+#define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
+    gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
         p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
         ld_dump)
+    // the 8-wave (512-query) tile exists for the product path only (MODE 0); the layout-dump hook stays on 4 waves
+#define INNR_GEMM_LAUNCH(RR)                                                                                    \
+    do {                                                                                                        \
+        if (MODE == 0 && p.waves == 8) INNR_GEMM_LAUNCH_W(RR, (MODE == 0 ? 8 : 4));                              \
+        else INNR_GEMM_LAUNCH_W(RR, 4);                                                                         \
+    } while (0)
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;
         case 512: INNR_GEMM_LAUNCH(8); break;
@@ -407,6 +417,7 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
         default: INNR_GEMM_LAUNCH(20); break;
     }
 #undef INNR_GEMM_LAUNCH
+#undef INNR_GEMM_LAUNCH_W
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
@@ -748,7 +759,7 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
     const bool cos = metric == INNR_METRIC_COSINE;
-    const GemmPlan p = plan_gemm(b, Q, 1);
+    const GemmPlan p = plan_gemm(b, Q, 1, /*waves=*/4);
     INNR_TRY(ensure_norms(b));
     if (cos) INNR_TRY(ensure_invnorms(b));
     INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
@@ -1360,9 +1371,9 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_TRY(bind_device(c));
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
-    INNR_TRY(c->q_norm.ensure(2 * round_up(Q, kBQ) * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(2 * round_up(Q, kBQmax) * sizeof(float)));
     float* qsum = c->q_norm.as<float>();
-    float* qnorm = qsum + round_up(Q, kBQ);
+    float* qnorm = qsum + round_up(Q, kBQmax);
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);

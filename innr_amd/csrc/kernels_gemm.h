@@ -31,18 +31,21 @@ namespace innr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGemmThreads = 256;
+// waves per block (template parameter WAVES): 4 = 256-query tile, two blocks per CU; 8 = 512-query tile, one block per
+// CU. Same speed at C2 (113.9 vs 114.1 ms); the 8-wave block streams the corpus once per 512 queries instead of once
+// per 256, halving the L2-miss traffic, so it is used whenever there are more than 256 queries.
 constexpr int kBC = 128;   // corpus rows per block tile
-constexpr int kBQ = 256;   // queries per block tile
+constexpr int kBQmax = 512;  // queries per block tile = 64 per wave
 constexpr int kBK = 16;    // K-step
 constexpr int kGemmBurst = kBC;  // most appends one tile can make to one query's list
 
 constexpr int kStages = 3;  // LDS ring: the DMA for K-step s+2 is issued during step s (two steps of cover)
 
+template <int WAVES>
 struct alignas(16) GemmLds {
     alignas(16) float A[kStages][kBK][kBC];  // 3 x 8 KiB: the corpus tile, shared by the block's four waves
-    uint32_t cnt[kBQ];
-    uint32_t thr[kBQ];
+    uint32_t cnt[64 * WAVES];
+    uint32_t thr[64 * WAVES];
 };
 constexpr uint32_t kStageBytesA = kBK * kBC * 4;
 
@@ -120,8 +123,8 @@ enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 //                ds_read_b32 feeds the four row tiles) and score = scale * (q.c) + invq[j]   (invq = offset*sum(q)):
 //                "path B" of SURVEY.md -- the f32 MFMA pipe, a quarter of the corpus bytes.
 // MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
-template <int KIND, int R, int MODE>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
+template <int KIND, int R, int MODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
     constexpr bool L2K = KIND == kGemmL2;
     const float* V = static_cast<const float*>(Vraw);
     const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
-    __shared__ GemmLds s;
+    constexpr int kGemmWaves = WAVES, kBQ = 64 * WAVES;
+    __shared__ GemmLds<WAVES> s;
     constexpr uint32_t cap = 64 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // Blocks b, b+8, ... share an XCD and its 4 MB L2 (round-robin dispatch). An XCD works on a group of `qtg`
@@ -173,6 +177,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             pa[j] = reinterpret_cast<const float*>(C8 + (size_t)(8 * (w & 1) + (lane >> 3)) * ldN + (size_t)t0 * kBC +
                                                    (size_t)(lane & 7) * 16);
             la[j] = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (w & 1));
+        } else if (kGemmWaves == 8) {  // 8 pieces of 2 rows, one per wave (pa[0] only)
+            pa[j] = V + (size_t)(2 * w + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
+            la[j] = lds_addr_uniform(&s.A[0][2 * w][0]);
         } else {
             pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
             la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         }
     };
     auto issue_a = [&](uint32_t stage_off) {
-        if (U8) {
+        if (U8 || kGemmWaves == 8) {
             glds16(pa[0], la[0] + stage_off);  // waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
         } else {
             glds16(pa[0], la[0] + stage_off);
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
             // they re-fetch the last step / wrap, into a stage and registers nobody reads), so the ops younger than
             // this group's operands (loaded one step ago, after the same group) are always 6 query loads + the corpus
             // DMA (f32: 2 ops, u8: 1). One unconditional wait: a branch here made hipcc copy the registers BEFORE it.
-            if (U8) use_after<7>(breg[2 * grp], breg[2 * grp + 1]);
+            if (U8 || kGemmWaves == 8) use_after<7>(breg[2 * grp], breg[2 * grp + 1]);
             else use_after<8>(breg[2 * grp], breg[2 * grp + 1]);
             const float2 bv[2] = {breg[2 * grp], breg[2 * grp + 1]};
             if (U8) {
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_filter_kernel(
         }
         // This wave's corpus pieces of K-step s+1 (issued one step ago) are in LDS; the youngest ops -- the corpus
         // pieces of s+2 and the 8 query loads of s+1 -- stay in flight.
-        if (U8) wait_but_youngest<9>();
+        if (U8 || kGemmWaves == 8) wait_but_youngest<9>();
         else wait_but_youngest<10>();
 #ifndef INNR_GEMM_PROBE_NOBAR  // tools/gemm_probe.hip
         __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step

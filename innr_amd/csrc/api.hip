@@ -356,7 +356,10 @@ struct GemmPlan {
 
 static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t force_waves = 0) {
     GemmPlan p;
-    p.waves = Q > 256 ? 8u : 4u;  // 512-query tiles halve the corpus re-reads; <= 256 queries fit one 4-wave tile
+    // 512-query tiles (8 waves) halve the corpus re-reads at equal speed when the epilogue is light (KP = 32: k <= 16;
+    // C2 113.9 vs 113.7 ms). With longer candidate lists the epilogue wants a second resident block to hide behind:
+    // k = 100 measured 126.5 ms on 4-wave blocks vs 130.0 on 8-wave ones (u8 at C3: 600 vs 621 ms).
+    p.waves = (Q > 256 && pick_kp(kout, 16) <= 32) ? 8u : 4u;
     if (const char* e = getenv("INNR_GEMM_WAVES")) p.waves = atoi(e) == 8 ? 8u : 4u;
     if (force_waves) p.waves = force_waves;
     const size_t bq = 64 * p.waves;

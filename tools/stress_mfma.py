@@ -11,7 +11,8 @@ from innr_amd import batch as B
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
-shapes = [(10_000, 48, 70, 10), (40_000, 48, 70, 10), (3_333, 64, 300, 33), (200_000, 32, 40, 10), (1_000_000, 128, 256, 10)]
+shapes = [(10_000, 48, 70, 10), (40_000, 48, 70, 10), (3_333, 64, 300, 33), (200_000, 32, 40, 10), (1_000_000, 128, 256, 10),
+          (500_000, 96, 1024, 10), (300_000, 64, 600, 16)]  # the last two run on 8-wave blocks (Q > 256, k <= 16)
 for (n, dim, nq, k) in shapes:
     vb = B.VerticalBatch.generate(n, dim, seed=7)
     qs = oracle.generate_uniform(nq, dim, 99)

@@ -18,7 +18,11 @@ constexpr int WAVES = INNR_GEMM_WAVES;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main(int argc, char** argv) {
     const size_t N = argc > 1 ? atol(argv[1]) : 10000000, D = 768, Q = 1024, ldN = (N + 255) / 256 * 256, Qpad = Q;
-    const uint32_t KP = 32, cap = 384, nqt = Q / (64 * WAVES), ns = (8 / WAVES) * 256 / nqt, ntiles = ldN / kBC, tps = (ntiles + ns - 1) / ns;
+#ifndef PROBE_R
+#define PROBE_R 6
+#define PROBE_KP 32
+#endif
+    const uint32_t KP = PROBE_KP, cap = 64 * PROBE_R, nqt = Q / (64 * WAVES), ns = (8 / WAVES) * 256 / nqt, ntiles = ldN / kBC, tps = (ntiles + ns - 1) / ns;
     float *V, *Qt;
     uint64_t* lists; uint32_t *counts, *gs, *err;
     CK(hipMalloc(&V, ldN * D * 4)); CK(hipMalloc(&Qt, D * Qpad * 4));
@@ -33,7 +37,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 4; ++it) {
         CK(hipMemset(gs, 0, (Qpad * KP + Qpad) * 4));
         hipEventRecord(a);
-        gemm_filter_kernel<kGemmDot, 6, 0, WAVES><<<nqt * ns, 64 * WAVES>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
+        gemm_filter_kernel<kGemmDot, PROBE_R, 0, WAVES><<<nqt * ns, 64 * WAVES>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
                                                                        1.0f, lists, counts, KP, err, gs, gs + Qpad * KP, nullptr, 0);
         hipEventRecord(b); CK(hipEventSynchronize(b));
         float ms; hipEventElapsedTime(&ms, a, b);

@@ -180,6 +180,13 @@ innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size
 innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
                              uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats);
 
+/* Several queries in one call (an addition; every query's result equals innr_maxsim_topk's). On the MFMA engine the
+ * queries share corpus passes four at a time. qtoks: Q queries of Tq_stride*dim floats, query i using its first tq[i]
+ * tokens (tq == NULL: Tq_stride each). out_doc / out_score: [Q][*out_k]. stats->gemm_ms sums the corpus scans. */
+innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks, size_t Q, const uint32_t* tq,
+                                   size_t Tq_stride, size_t dim, size_t k, int engine, uint64_t* out_doc, float* out_score,
+                                   size_t* out_k, innr_knn_stats* stats);
+
 /* ---- L2 variants of the batch module (exact engine, one query) -------------------------------------- */
 /* batch_dimension_variance (batch.rs:572-592): out[D]; sequential sums in the reference's order, cached per batch */
 innr_status innr_batch_dimension_variance(innr_batch* b, float* out);

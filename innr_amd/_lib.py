@@ -102,6 +102,8 @@ SIGNATURES = {
     "innr_docs_set_index_base": (C.c_int, [_vp, C.c_uint64]),
     "innr_maxsim_scores": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp]),
     "innr_maxsim_topk": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_maxsim_topk_multi": (C.c_int, [_vp, C.c_int, _vp, _sz, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp,
+                                        C.POINTER(KnnStats)]),
     "innr_batch_dimension_variance": (C.c_int, [_vp, _vp]),
     "innr_batch_knn_filtered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _szp]),
     "innr_batch_knn_reordered": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _szp]),

@@ -1607,7 +1607,7 @@ innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size
 
 // top-KP of the dense score array c->scores -> c->sel / c->sel_cnt (order: score desc, document index asc -- the
 // caller's stable sort in the reference example, examples/maxsim_colbert.rs:186-187)
-static innr_status maxsim_select(innr_docs* d, uint32_t KP) {
+static innr_status maxsim_select(innr_docs* d, uint32_t KP, const float* sc) {
     innr_ctx* c = d->ctx;
     const uint32_t cap = exact_cap(KP);
     const size_t nchunks = (d->ndocs + 255) / 256;
@@ -1619,7 +1619,6 @@ static innr_status maxsim_select(innr_docs* d, uint32_t KP) {
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
     uint32_t* err = c->flags.as<uint32_t>();
-    const float* sc = c->scores.as<float>();
     switch (cap) {
         case 384: dense_filter_kernel<6><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
         case 768: dense_filter_kernel<12><<<nb, 256, 0, c->stream>>>(sc, (uint32_t)d->ndocs, lists, counts, KP, cps, err); break;
@@ -1658,16 +1657,11 @@ static bool maxsim_mfma_eligible(const innr_docs* d, size_t Tq) {
 
 // MFMA engine: approximate scores of every document (c->scores), top-KP by approximate score, exact re-score of
 // those KP documents, proof. Results in c->out_idx / c->out_score; *proven = false -> the caller redoes it exactly.
-static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t kout, bool* proven,
-                                    uint32_t* kp_out) {
-    innr_ctx* c = d->ctx;
+// error bound of the approximate document score: per (token, query token) pair the MFMA fma chain and
+// the reference's mul-then-add 4-way sum differ by <= (2 dim + 8) u |q_j| |d_i|; the max over tokens is 1-Lipschitz; the
+// two Tq-term sums (tree here, sequential there) add <= 2 Tq u sum_j |best_j|. Returns false when no finite bound exists.
+static bool maxsim_error_bound(const innr_docs* d, int cosine, const float* qtok, size_t Tq, float* E) {
     const size_t dim = d->dim;
-    *proven = false;
-    INNR_TRY(maxsim_ensure_token_norms(d));
-    if (!(d->max_norm - d->max_norm == 0.0f)) return INNR_OK;  // non-finite token somewhere: exact engine
-    // error bound of the approximate document score: per (token, query token) pair the MFMA fma chain
-    // and the reference's mul-then-add 4-way sum differ by <= (2 dim + 8) u |q_j| |d_i|; the max over tokens is
-    // 1-Lipschitz; the two 32-term sums (tree here, sequential there) add <= 2 Tq u sum_j |best_j|.
     double qsum = 0.0;
     for (size_t j = 0; j < Tq; ++j) {
         double ss = 0.0;
@@ -1677,78 +1671,126 @@ static innr_status maxsim_topk_mfma(innr_docs* d, int cosine, const float* qtok,
     const double u = 5.9604644775390625e-08;  // 2^-24
     const double Ed = cosine ? 1.05 * (2.0 * dim + 32.0 + 2.0 * Tq) * u * (double)Tq
                              : 1.05 * (2.0 * dim + 8.0 + 2.0 * Tq) * u * (double)d->max_norm * qsum;
-    if (!(Ed - Ed == 0.0) || Ed > 3.0e38) return INNR_OK;
-    const float E = (float)(Ed * 1.0000002);
-    INNR_TRY(maxsim_stage_query(d, cosine, qtok, Tq));
-    INNR_TRY(c->scores.ensure(d->ndocs * sizeof(float)));
-    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));
-    float* qB = c->q_kmajor.as<float>();
-    float* approx = c->scores.as<float>();
-    const size_t Tq_pad = round_up(Tq, kMsQ);
-    float* qscale = c->q_norm.as<float>() + Tq_pad;
+    if (!(Ed - Ed == 0.0) || Ed > 3.0e38) return false;
+    *E = (float)(Ed * 1.0000002);
+    return true;
+}
+
+// Approximate scores of `nqr` queries (1, 2 or 4; more than one only with <= 32 tokens each and a tile-unrolled dim)
+// for every document: c->scores[qi * ndocs + doc]. Query qi = qtoks[qi], Tqs[qi] tokens.
+static innr_status maxsim_approx(innr_docs* d, int cosine, const float* const* qtoks, const size_t* Tqs, int nqr) {
+    innr_ctx* c = d->ctx;
+    const size_t dim = d->dim;
+    size_t Tq_pad = 0;
+    for (int qi = 0; qi < nqr; ++qi) Tq_pad = std::max(Tq_pad, round_up(Tqs[qi], kMsQ));
+    const size_t rows = (size_t)nqr * Tq_pad;  // query qi occupies rows [qi*Tq_pad, (qi+1)*Tq_pad), zero padded
+    INNR_TRY(c->q_row.ensure(rows * dim * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(2 * rows * sizeof(float)));
+    INNR_HIP_CHECK(hipMemsetAsync(c->q_row.p, 0, rows * dim * sizeof(float), c->stream));
+    for (int qi = 0; qi < nqr; ++qi)
+        INNR_HIP_CHECK(copy_in(c, c->q_row.as<float>() + (size_t)qi * Tq_pad * dim, qtoks[qi], Tqs[qi] * dim * sizeof(float)));
+    float* qscale = c->q_norm.as<float>() + rows;
     if (cosine) {
-        maxsim_query_scale_kernel<<<(unsigned)((Tq_pad + 63) / 64), 64, 0, c->stream>>>(c->q_norm.as<float>(), (uint32_t)Tq_pad, qscale);
+        query_token_sq_kernel<<<(unsigned)((rows + 63) / 64), 64, 0, c->stream>>>(c->q_row.as<float>(), (uint32_t)rows,
+                                                                                 (uint32_t)dim, c->q_norm.as<float>());
+        maxsim_query_scale_kernel<<<(unsigned)((rows + 63) / 64), 64, 0, c->stream>>>(c->q_norm.as<float>(), (uint32_t)rows, qscale);
         INNR_HIP_CHECK(hipGetLastError());
     }
-    const size_t lds = dim * 32 * sizeof(float);  // [dim/8][64][4]
+    INNR_TRY(c->scores.ensure((size_t)nqr * d->ndocs * sizeof(float)));
+    INNR_TRY(c->q_kmajor.ensure((size_t)nqr * kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));
+    INNR_TRY(c->misc.ensure(16384));  // [0,4K) norm scratch, [4K,8K) per-pass token counts, [8K,..) candidate ids / exact scores
+    float* qB = c->q_kmajor.as<float>();
+    float* approx = c->scores.as<float>();
+    const size_t qb_stride = dim * 32;  // floats per packed query: [dim/8][64][4]
+    const size_t lds = (size_t)nqr * qb_stride * sizeof(float);
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((d->ndocs + 3) / 4, (size_t)c->num_cus * 8));
-    for (size_t p0 = 0; p0 < Tq; p0 += kMsQ) {
-        const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
-        maxsim_pack_mfma_kernel<<<(unsigned)((dim * 32 + 255) / 256), 256, 0, c->stream>>>(c->q_row.as<float>() + p0 * dim,
-                                                                                          (uint32_t)dim, qB);
-#define INNR_MS_TILE(COSV, NBV)                                                                                         \
-    maxsim_mfma_tile_kernel<COSV, NBV><<<blocks, kMsThreads, lds, c->stream>>>(                                           \
-        d->tok, d->doc_len, COSV ? d->tok_inv : nullptr, (uint32_t)d->ndocs, (uint32_t)d->T, qB, nq,                      \
+    const bool tiled = dim % 32 == 0 && dim <= 128 && !getenv("INNR_MAXSIM_GENERIC");
+    uint32_t* nq_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 4096);  // token counts of this pass
+    for (size_t p0 = 0; p0 < Tq_pad; p0 += kMsQ) {
+        uint32_t nq_host[4] = {0, 0, 0, 0};
+        for (int qi = 0; qi < nqr; ++qi) {
+            nq_host[qi] = Tqs[qi] > p0 ? (uint32_t)std::min<size_t>(kMsQ, Tqs[qi] - p0) : 0u;
+            maxsim_pack_mfma_kernel<<<(unsigned)((dim * 32 + 255) / 256), 256, 0, c->stream>>>(
+                c->q_row.as<float>() + ((size_t)qi * Tq_pad + p0) * dim, (uint32_t)dim, qB + (size_t)qi * qb_stride);
+        }
+        INNR_HIP_CHECK(copy_in(c, nq_dev + 4 * (p0 / kMsQ), nq_host, sizeof(nq_host)));
+        const uint32_t* nqp = nq_dev + 4 * (p0 / kMsQ);
+#define INNR_MS_TILE(COSV, NBV, NQV)                                                                                    \
+    maxsim_mfma_tile_kernel<COSV, NBV, NQV><<<blocks, kMsThreads, lds, c->stream>>>(                                     \
+        d->tok, d->doc_len, COSV ? d->tok_inv : nullptr, (uint32_t)d->ndocs, (uint32_t)d->T, qB, nqp,                     \
         COSV ? qscale + p0 : nullptr, approx, approx, p0 == 0)
-        const bool tiled = dim % 32 == 0 && dim <= 128 && !getenv("INNR_MAXSIM_GENERIC");
-        if (tiled && cosine) {
-            switch (dim / 32) {
-                case 1: INNR_MS_TILE(true, 1); break;
-                case 2: INNR_MS_TILE(true, 2); break;
-                case 3: INNR_MS_TILE(true, 3); break;
-                default: INNR_MS_TILE(true, 4); break;
-            }
+#define INNR_MS_TILE_NB(COSV, NQV)                                                                                      \
+    switch (dim / 32) {                                                                                                 \
+        case 1: INNR_MS_TILE(COSV, 1, NQV); break;                                                                      \
+        case 2: INNR_MS_TILE(COSV, 2, NQV); break;                                                                      \
+        case 3: INNR_MS_TILE(COSV, 3, NQV); break;                                                                      \
+        default: INNR_MS_TILE(COSV, 4, NQV); break;                                                                     \
+    }
+        if (tiled && nqr == 4) {
+            if (cosine) { INNR_MS_TILE_NB(true, 4) } else { INNR_MS_TILE_NB(false, 4) }
+        } else if (tiled && nqr == 2) {
+            if (cosine) { INNR_MS_TILE_NB(true, 2) } else { INNR_MS_TILE_NB(false, 2) }
         } else if (tiled) {
-            switch (dim / 32) {
-                case 1: INNR_MS_TILE(false, 1); break;
-                case 2: INNR_MS_TILE(false, 2); break;
-                case 3: INNR_MS_TILE(false, 3); break;
-                default: INNR_MS_TILE(false, 4); break;
-            }
+            if (cosine) { INNR_MS_TILE_NB(true, 1) } else { INNR_MS_TILE_NB(false, 1) }
+        } else if (nqr != 1) {
+            set_error("internal: multi-query maxsim needs the tile-unrolled kernel");
+            return INNR_E_UNSUPPORTED;
         } else if (cosine)
             maxsim_mfma_kernel<true><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, d->tok_inv, (uint32_t)d->ndocs,
-                                                                             (uint32_t)d->T, (uint32_t)dim, qB, nq, qscale + p0,
-                                                                             approx, approx, p0 == 0);
+                                                                             (uint32_t)d->T, (uint32_t)dim, qB, nq_host[0],
+                                                                             qscale + p0, approx, approx, p0 == 0);
         else
             maxsim_mfma_kernel<false><<<blocks, kMsThreads, lds, c->stream>>>(d->tok, d->doc_len, nullptr, (uint32_t)d->ndocs,
-                                                                              (uint32_t)d->T, (uint32_t)dim, qB, nq, nullptr,
-                                                                              approx, approx, p0 == 0);
+                                                                              (uint32_t)d->T, (uint32_t)dim, qB, nq_host[0],
+                                                                              nullptr, approx, approx, p0 == 0);
+#undef INNR_MS_TILE_NB
 #undef INNR_MS_TILE
         INNR_HIP_CHECK(hipGetLastError());
     }
-    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    return INNR_OK;
+}
+
+// Second half of the MFMA engine for ONE query: top-KP of its approximate scores, exact re-score of those documents,
+// final order + proof. Results at c->out_idx / c->out_score + out_off; *proven = false -> the caller redoes it exactly.
+static innr_status maxsim_post(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t kout, float E,
+                               const float* approx, size_t out_off, bool* proven, uint32_t* kp_out) {
+    innr_ctx* c = d->ctx;
     const uint32_t KP = pick_kp(kout, 16);
     *kp_out = KP;
-    INNR_TRY(maxsim_select(d, KP));
-    // exact re-score of the candidates, in the selection's order
-    INNR_TRY(c->misc.ensure(4096 + KP * (sizeof(uint32_t) + sizeof(float))));
-    uint32_t* ids = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 4096);
+    INNR_TRY(maxsim_select(d, KP, approx));
+    INNR_TRY(c->misc.ensure(16384));  // KP <= 256: ids + exact scores fit behind the first 8 KiB
+    uint32_t* ids = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 8192);
     float* exact = reinterpret_cast<float*>(ids + KP);
     maxsim_cand_ids_kernel<<<(KP + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), KP, ids);
     INNR_HIP_CHECK(hipGetLastError());
     const size_t ncand = std::min<size_t>(KP, d->ndocs);
+    INNR_TRY(maxsim_stage_query(d, cosine, qtok, Tq));  // the exact engine reads the query from c->q_row / c->q_norm
     INNR_TRY(maxsim_scan_exact(d, cosine, Tq, ids, ncand, exact));
-    INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
-    INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
     uint32_t* flag = c->flags.as<uint32_t>() + 64;
     maxsim_finish_kernel<<<1, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), exact, (uint32_t)kout,
-                                                   (uint32_t)d->ndocs, E, d->index_base, c->out_idx.as<uint64_t>(),
-                                                   c->out_score.as<float>(), flag);
+                                                   (uint32_t)d->ndocs, E, d->index_base, c->out_idx.as<uint64_t>() + out_off,
+                                                   c->out_score.as<float>() + out_off, flag);
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t ok = 0;
     INNR_HIP_CHECK(copy_out(c, &ok, flag, 4));
     INNR_HIP_CHECK(ctx_sync(c));
     *proven = ok != 0;
+    return INNR_OK;
+}
+
+// exact engine for one query: all-document scores -> top-k at c->out_idx / c->out_score + out_off
+static innr_status maxsim_topk_exact(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t kout, size_t out_off,
+                                     uint32_t* kp_out) {
+    innr_ctx* c = d->ctx;
+    INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, d->dim));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    const uint32_t KP = pick_kp(kout, 0);
+    *kp_out = KP;
+    INNR_TRY(maxsim_select(d, KP, c->scores.as<float>()));
+    emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, 1, (uint32_t)kout, false,
+                                                                              d->index_base, c->out_idx.as<uint64_t>() + out_off,
+                                                                              c->out_score.as<float>() + out_off);
+    INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
 
@@ -1784,8 +1826,17 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     uint32_t KP = 0;
     int used = INNR_KNN_EXACT;
     float scan_ms = 0.0f;
+    INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
     if (use_mfma) {
-        INNR_TRY(maxsim_topk_mfma(d, cosine, qtok, Tq, kout, &proven, &KP));
+        float E = 0.0f;
+        INNR_TRY(maxsim_ensure_token_norms(d));
+        // a non-finite token somewhere, or no finite bound: nothing can be proven, go straight to the exact engine
+        if ((d->max_norm - d->max_norm == 0.0f) && maxsim_error_bound(d, cosine, qtok, Tq, &E)) {
+            INNR_TRY(maxsim_approx(d, cosine, &qtok, &Tq, 1));
+            INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+            INNR_TRY(maxsim_post(d, cosine, qtok, Tq, kout, E, c->scores.as<float>(), 0, &proven, &KP));
+        }
         if (proven) {
             used = INNR_KNN_MFMA;
             (void)hipEventElapsedTime(&scan_ms, c->ev[2], c->ev[3]);
@@ -1793,16 +1844,7 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     }
     if (!proven) {
         INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-        INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
-        INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-        KP = pick_kp(kout, 0);
-        INNR_TRY(maxsim_select(d, KP));
-        INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
-        INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
-        emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, 1, (uint32_t)kout,
-                                                                                  false, d->index_base, c->out_idx.as<uint64_t>(),
-                                                                                  c->out_score.as<float>());
-        INNR_HIP_CHECK(hipGetLastError());
+        INNR_TRY(maxsim_topk_exact(d, cosine, qtok, Tq, kout, 0, &KP));
     }
     INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     INNR_TRY(check_errflag(c));
@@ -1817,6 +1859,110 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
         float ms = 0.0f;
         if (used == INNR_KNN_MFMA) stats->gemm_ms = scan_ms;  // the approximate scan kernel(s)
         else if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) stats->gemm_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
+    }
+    return INNR_OK;
+}
+
+// Several queries against the same corpus in one call (an addition: the reference scores one (query, document) pair
+// per call). Queries are taken 4 (then 2, then 1) per corpus pass on the MFMA engine, which turns the scan from
+// HBM-bound into MFMA-bound; every query's result is the same as innr_maxsim_topk's.
+// qtoks: Q queries of Tq_stride*dim floats each, query i using its first tq[i] tokens (tq == NULL: all Tq_stride).
+innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks, size_t Q, const uint32_t* tq,
+                                   size_t Tq_stride, size_t dim, size_t k, int engine, uint64_t* out_doc, float* out_score,
+                                   size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!d || !out_k || (!qtoks && Q * Tq_stride * dim)) return INNR_E_BAD_ARG;
+    if (engine != INNR_KNN_AUTO && engine != INNR_KNN_EXACT && engine != INNR_KNN_MFMA) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    innr_ctx* c = d->ctx;
+    INNR_TRY(bind_device(c));
+    if (dim != d->dim && Tq_stride && d->T) {
+        set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
+        return INNR_E_DIM_MISMATCH;
+    }
+    if (d->ndocs == 0 || k == 0 || Q == 0) return INNR_OK;
+    const size_t kout = std::min(k, d->ndocs);
+    if (kout > INNR_MAX_K) {
+        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
+    std::vector<size_t> Tqs(Q);
+    size_t tq_max = 0, tq_min = Tq_stride;
+    for (size_t i = 0; i < Q; ++i) {
+        Tqs[i] = tq ? std::min<size_t>(tq[i], Tq_stride) : Tq_stride;
+        tq_max = std::max(tq_max, Tqs[i]);
+        tq_min = std::min(tq_min, Tqs[i]);
+    }
+    const bool eligible = tq_min > 0 && maxsim_mfma_eligible(d, tq_min) && pick_kp(kout, 16) <= 256;
+    if (engine == INNR_KNN_MFMA && !eligible) {
+        set_error("maxsim MFMA engine needs T > 16, dim %% 8 == 0, 8 <= dim <= 512, non-empty queries and k <= 240");
+        return INNR_E_UNSUPPORTED;
+    }
+    bool use_mfma = engine == INNR_KNN_MFMA || (engine == INNR_KNN_AUTO && eligible && d->ndocs >= 4096);
+    INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(Q * kout * sizeof(float)));
+    if (use_mfma) {
+        INNR_TRY(maxsim_ensure_token_norms(d));
+        if (!(d->max_norm - d->max_norm == 0.0f)) use_mfma = false;  // a non-finite token: nothing can be proven
+    }
+    // groups of 4 / 2 queries share a corpus pass when the tile-unrolled kernel applies and every query fits one pass
+    const bool groupable = use_mfma && dim % 32 == 0 && dim <= 128 && tq_max <= (size_t)kMsQ && !getenv("INNR_MAXSIM_GENERIC");
+    std::vector<uint8_t> done(Q, 0);
+    uint32_t KP = 0, nfallback = 0;
+    float scan_ms = 0.0f;
+    for (size_t i = 0; use_mfma && i < Q;) {
+        const int g = !groupable ? 1 : (Q - i >= 4 ? 4 : (Q - i >= 2 ? 2 : 1));
+        const float* ptrs[4];
+        size_t tqs[4];
+        float E[4];
+        bool bounded = true;
+        for (int j = 0; j < g; ++j) {
+            ptrs[j] = qtoks + (i + j) * Tq_stride * dim;
+            tqs[j] = Tqs[i + j];
+            bounded = bounded && maxsim_error_bound(d, cosine, ptrs[j], tqs[j], &E[j]);
+        }
+        if (bounded) {
+            INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+            INNR_TRY(maxsim_approx(d, cosine, ptrs, tqs, g));
+            INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+            for (int j = 0; j < g; ++j) {
+                bool proven = false;
+                INNR_TRY(maxsim_post(d, cosine, ptrs[j], tqs[j], kout, E[j], c->scores.as<float>() + (size_t)j * d->ndocs,
+                                     (i + j) * kout, &proven, &KP));
+                done[i + j] = proven ? 1 : 0;
+            }
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) scan_ms += ms;
+        }
+        i += g;
+    }
+    for (size_t i = 0; i < Q; ++i) {  // exact engine: unproven queries, or everything when the MFMA engine is off
+        if (done[i]) continue;
+        if (use_mfma) ++nfallback;
+        INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+        INNR_TRY(maxsim_topk_exact(d, cosine, qtoks + i * Tq_stride * dim, Tqs[i], kout, i * kout, &KP));
+        if (!use_mfma) {
+            INNR_HIP_CHECK(ctx_sync(c));
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) scan_ms += ms;
+        }
+    }
+    INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    INNR_TRY(check_errflag(c));
+    INNR_HIP_CHECK(copy_out(c, out_doc, c->out_idx.p, Q * kout * sizeof(uint64_t)));
+    INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * kout * sizeof(float)));
+    INNR_HIP_CHECK(ctx_sync(c));
+    *out_k = kout;
+    if (stats) {
+        stats->engine = use_mfma ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+        stats->candidates_kept = KP;
+        stats->queries_fallback = nfallback;
+        stats->gemm_ms = scan_ms;
+        float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     return INNR_OK;

@@ -387,16 +387,21 @@ __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_kernel(
 // (every VMEM op visible to the compiler, no register copies of in-flight loads), so hipcc's own s_waitcnt vmcnt(N)
 // comes out as the exact count of younger requests; past its last tile a wave re-requests the current one (mapped
 // addresses, registers nobody reads) so that the loop body is branch-free.
-template <bool COS, int NB>
+// NQ queries per corpus pass (1, 2 or 4; all with <= 32 tokens): the tile is multiplied against each query's operands
+// before its registers are re-requested, so the corpus is streamed once for NQ queries and the pass turns MFMA-bound
+// (NQ x 64 MFMAs per 16 KiB tile). Query qi's operands sit at qB + qi * (4*NB*64*4) floats, its token count in nq[qi],
+// its scale row at q_scale + 32*qi, its scores in out + qi * ndocs. partial_in/first_pass (queries of more than 32
+// tokens, accumulated over passes) are honoured for NQ == 1 only.
+template <bool COS, int NB, int NQ>
 __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_tile_kernel(
     const float* __restrict__ tok, const uint32_t* __restrict__ doc_len, const float* __restrict__ tok_inv /*COS, padded*/,
-    uint32_t ndocs, uint32_t T, const float* __restrict__ qB /*[4*NB][64][4]*/, uint32_t nq,
-    const float* __restrict__ q_scale /*[32] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
+    uint32_t ndocs, uint32_t T, const float* __restrict__ qB /*[NQ][4*NB][64][4]*/, const uint32_t* __restrict__ nq /*[NQ]*/,
+    const float* __restrict__ q_scale /*[NQ][32] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
     bool first_pass) {
     constexpr uint32_t dim = 32 * NB, nch = 4 * NB;
     extern __shared__ __attribute__((aligned(16))) float s_qB[];
     const int lane = threadIdx.x & 63;
-    for (uint32_t i = threadIdx.x; i < nch * 64; i += kMsThreads)
+    for (uint32_t i = threadIdx.x; i < NQ * nch * 64; i += kMsThreads)
         reinterpret_cast<float4*>(s_qB)[i] = reinterpret_cast<const float4*>(qB)[i];
     __syncthreads();
     const float4* bl = reinterpret_cast<const float4*>(s_qB) + lane;
@@ -405,7 +410,13 @@ __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_tile_kernel(
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kMsThreads + threadIdx.x) >> 6);
     const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
     const uint32_t j = lane & 31, h = lane >> 5;
-    const float qs = COS ? q_scale[j] : 1.0f;
+    float qs[NQ];
+    uint32_t nqv[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        qs[qi] = COS ? q_scale[32 * qi + j] : 1.0f;
+        nqv[qi] = nq[qi];
+    }
     if (wave >= ndocs) return;  // wave-uniform, after the only barrier
     auto doclen = [&](uint32_t d) { return doc_len ? min(doc_len[d], T) : T; };
     // rows past the document's end re-read its last token (mapped memory) and are masked out of the max
@@ -425,7 +436,9 @@ __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_tile_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) iv[q] = ldinv(invptr(cdoc, 0, q));
     }
-    float best = -INFINITY;
+    float best[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) best[qi] = -INFINITY;
     while (true) {  // every exit condition is wave-uniform
         uint32_t ndoc = cdoc, nt0 = ct0 + 32, nlen = clen;
         if (nt0 >= clen) {
@@ -435,50 +448,61 @@ __global__ __launch_bounds__(kMsThreads) void maxsim_mfma_tile_kernel(
         }
         const bool has_next = ndoc < ndocs;
         const float* nrp = has_next ? rowptr(ndoc, nt0) : rp;
-        msf32x16 acc;
+        msf32x16 acc[NQ];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+        for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[qi][g] = 0.0f;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 b4 = bl[(size_t)(4 * b + u) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].x, b4.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].y, b4.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].z, b4.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].w, b4.w, acc, 0, 0, 0);
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const float4 b4 = bl[(size_t)(qi * nch + 4 * b + u) * 64];
+                    acc[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].x, b4.x, acc[qi], 0, 0, 0);
+                    acc[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].y, b4.y, acc[qi], 0, 0, 0);
+                    acc[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].z, b4.z, acc[qi], 0, 0, 0);
+                    acc[qi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[b][u].w, b4.w, acc[qi], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) a[b][u] = *reinterpret_cast<const float4*>(nrp + 32 * b + 8 * u);
         }
-        float m = -INFINITY;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const uint32_t row = ct0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            float v = acc[g];
-            if (COS) {
-                const float4 t = iv[g >> 2];
-                v *= (g & 3) == 0 ? t.x : ((g & 3) == 1 ? t.y : ((g & 3) == 2 ? t.z : t.w));
+        for (int qi = 0; qi < NQ; ++qi) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const uint32_t row = ct0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                float v = acc[qi][g];
+                if (COS) {
+                    const float4 t = iv[g >> 2];
+                    v *= (g & 3) == 0 ? t.x : ((g & 3) == 1 ? t.y : ((g & 3) == 2 ? t.z : t.w));
+                }
+                m = (row < clen) ? fmaxf(m, v) : m;
             }
-            m = (row < clen) ? fmaxf(m, v) : m;
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            best[qi] = fmaxf(best[qi], m);
         }
         if (COS) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) iv[q] = ldinv(has_next ? invptr(ndoc, nt0, q) : invptr(cdoc, ct0, q));
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        best = fmaxf(best, m);
         if (ndoc != cdoc) {  // last tile of this document: sum over query tokens, publish
-            float v = (j < nq) ? best * qs : 0.0f;
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) {
-                float total = (first_pass ? 0.0f : partial_in[cdoc]) + v;
-                if (total != total) total = INFINITY;  // a NaN anywhere: force the document into the exact re-score
-                out[cdoc] = (clen == 0) ? 0.0f : total;
+            for (int qi = 0; qi < NQ; ++qi) {
+                float v = (j < nqv[qi]) ? best[qi] * qs[qi] : 0.0f;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) {
+                    float total = ((NQ > 1 || first_pass) ? 0.0f : partial_in[cdoc]) + v;
+                    if (total != total) total = INFINITY;  // a NaN anywhere: force the document into the exact re-score
+                    out[(size_t)qi * ndocs + cdoc] = (clen == 0) ? 0.0f : total;
+                }
+                best[qi] = -INFINITY;
             }
-            best = -INFINITY;
         }
         if (!has_next) break;
         cdoc = ndoc;

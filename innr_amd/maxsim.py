@@ -124,6 +124,34 @@ class DocumentCorpus:
         r = int(out_k.value)
         return idx[:r].copy(), sc[:r].copy()
 
+    def topk_multi(self, queries, k: int, cosine: bool = False, stats: Optional[KnnStats] = None,
+                   engine: int = _lib.KNN_AUTO):
+        """Several queries (a list of [Tq_i, dim] token matrices) in one call; on the MFMA engine they share corpus
+        passes four at a time. Returns (indices [Q, k'], scores [Q, k']), row i = topk(queries[i], k)."""
+        qs = [self._q(q) for q in queries]
+        nq = len(qs)
+        kk = max(min(int(k), self._n), 1)
+        idx = np.empty((max(nq, 1), kk), dtype=np.uint64)
+        sc = np.empty((max(nq, 1), kk), dtype=np.float32)
+        if nq == 0:
+            return idx[:0], sc[:0]
+        stride = max(max(q.shape[0] for q in qs), 1)
+        packed = np.zeros((nq, stride, self._dim), dtype=np.float32)
+        tq = np.zeros(nq, dtype=np.uint32)
+        for i, q in enumerate(qs):
+            if q.size and q.shape[1] != self._dim:
+                raise InnrPanic(f"dimension mismatch (doc): query dim {q.shape[1]}, document dim {self._dim}")
+            packed[i, :q.shape[0]] = q
+            tq[i] = q.shape[0]
+        out_k = C.c_size_t(0)
+        st = stats if stats is not None else KnnStats()
+        check(load().innr_maxsim_topk_multi(self._h, 1 if cosine else 0, C.c_void_p(packed.ctypes.data), nq,
+                                            C.c_void_p(tq.ctypes.data), stride, self._dim, int(k), int(engine),
+                                            C.c_void_p(idx.ctypes.data), C.c_void_p(sc.ctypes.data), C.byref(out_k),
+                                            C.byref(st)))
+        r = int(out_k.value)
+        return idx[:, :r].copy(), sc[:, :r].copy()
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             if getattr(self._ctx, "handle", None):

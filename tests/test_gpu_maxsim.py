@@ -191,3 +191,27 @@ def test_full_size_properties_c4(M):
             toks[t] = rows[t] / np.float32(np.sqrt(ss))
         assert np.float32(oracle.maxsim(q, toks)).view(np.uint32) == sc[r].view(np.uint32)
     print(f"C4 maxsim: scan {st.gemm_ms:.2f} ms, total {st.total_ms:.2f} ms")
+
+
+@pytest.mark.parametrize("ndocs,T,dim,k", [(5000, 64, 128, 10), (3000, 40, 64, 100), (4200, 33, 96, 7), (600, 20, 48, 5)])
+def test_maxsim_topk_multi_equals_single_queries(M, ndocs, T, dim, k):
+    import innr_amd
+    toks = _tokens(ndocs, T, dim, 31)
+    lens = np.array([max(1, (i * 11) % (T + 1)) for i in range(ndocs)], dtype=np.uint32)
+    dc = M.DocumentCorpus.from_tokens(toks, lens)
+    queries = [_tokens(1, tq, dim, 100 + tq)[0] for tq in (32, 5, 17, 1, 32, 9, 40)]  # 7 queries: 4 + 2 + 1; one > 32 tokens
+    for cosine in (False, True):
+        for qset in (queries[:6], queries):  # with the 40-token query the groups fall back to one query per pass
+            st = innr_amd.KnnStats()
+            idx, sc = dc.topk_multi(qset, k, cosine=cosine, stats=st, engine=innr_amd.KNN_MFMA if dim % 8 == 0 and T > 16 else innr_amd.KNN_AUTO)
+            assert idx.shape == (len(qset), min(k, ndocs))
+            for i, q in enumerate(qset):
+                s = _oracle_scores(q, toks, lens, cosine=cosine)
+                order = np.argsort(-s.astype(np.float64), kind="stable")[:k]
+                assert idx[i].tolist() == order.tolist() and bits_equal(sc[i], s[order]), (cosine, i)
+    # exact engine and empty inputs
+    idx, sc = dc.topk_multi(queries[:3], k, engine=innr_amd.KNN_EXACT)
+    i1, s1 = dc.topk(queries[1], k, engine=innr_amd.KNN_EXACT)
+    assert idx[1].tolist() == i1.tolist() and bits_equal(sc[1], s1)
+    idx, sc = dc.topk_multi([], k)
+    assert idx.shape[0] == 0

@@ -262,6 +262,12 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
         // first group of a step, right after the barrier, exposes LDS latency), 16 MFMAs, then the two B registers the
         // group just consumed are reloaded for the next K-step.
         float4 avs[2][2];
+        // The per-lane part of the fragment address is re-derived from the lane id in every step (two VALU ops behind an
+        // opaque copy): hoisted out of the loop it is one more loop-invariant VGPR, and in the cosine / L2 instantiations
+        // hipcc spilled exactly that one -- a scratch reload + s_waitcnt vmcnt(0) at the top of every K-step, which also
+        // drained the DMA and the query loads in flight (L2: 125.6 ms).
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
         auto read_frags = [&](int grp, int set) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -269,9 +275,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                 if (U8) {  // 4 codes (rows 4r..4r+3 of dimension k) in one dword; widened to f32 right before the MFMAs
                     const uint8_t* a8 = reinterpret_cast<const uint8_t*>(&s.A[st][0][0]);
                     avs[set][h].x = __uint_as_float(
-                        *reinterpret_cast<const uint32_t*>(a8 + (2 * kp + (lane >> 5)) * kBC + 4 * (lane & 31)));
+                        *reinterpret_cast<const uint32_t*>(a8 + (2 * kp + (lane_k >> 5)) * kBC + 4 * (lane_k & 31)));
                 } else {
-                    avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane >> 5)][4 * (lane & 31)]);
+                    avs[set][h] = *reinterpret_cast<const float4*>(&s.A[st][2 * kp + (lane_k >> 5)][4 * (lane_k & 31)]);
                 }
             }
         };

@@ -87,6 +87,8 @@ struct innr_ctx {
     DevBuf flags;     // error flag + per-query fallback flags
     DevBuf out_idx;   // staging for host-pointer entry points
     DevBuf out_score;
+    DevBuf seed_idx;   // threshold seeding: exact top-KP of a corpus prefix (indices unused, scores -> bounds)
+    DevBuf seed_score;
     DevBuf misc;
 };
 
@@ -299,13 +301,28 @@ static innr_status launch_scan_filter(innr_batch* b, int metric, const float* dQ
 }
 
 // Exact kNN for queries [q0, q0+nq) (row-major on device, stride ldq): results to d_out_* at row q0.
-static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, size_t ldq, const float* dQn,
+// limit_n != 0: only the first limit_n vectors of the batch take part (the GEMM engine's threshold seeding).
+static innr_status knn_exact_range(innr_batch* b_full, int metric, const float* dQ, size_t ldq, const float* dQn,
                                    size_t q0, size_t nq, size_t kout, uint64_t* d_out_idx, float* d_out_score,
-                                   const ScanExt& ext = ScanExt()) {
-    innr_ctx* c = b->ctx;
+                                   const ScanExt& ext = ScanExt(), size_t limit_n = 0) {
+    innr_ctx* c = b_full->ctx;
+    innr_batch view;  // same device buffers, shorter N (masks) -- never freed, it owns nothing
+    innr_batch* b = b_full;
+    if (limit_n && limit_n < b_full->N) {
+        view.ctx = b_full->ctx;
+        view.N = limit_n;
+        view.D = b_full->D;
+        view.ldN = b_full->ldN;
+        view.Dpad = b_full->Dpad;
+        view.V = b_full->V;
+        view.norms = b_full->norms;
+        view.index_base = b_full->index_base;
+        b = &view;
+    }
     const uint32_t KP = pick_kp(kout, 0);
     const uint32_t cap = exact_cap(KP);
-    const size_t nchunks = b->ldN / kScanChunk;
+    const size_t cols = (b == &view) ? round_up(limit_n, kScanChunk) : b->ldN;  // columns that are scanned
+    const size_t nchunks = cols / kScanChunk;
     // wave slots: fill the chip to the occupancy the register budget allows (HBM latency needs the waves: the
     // single-query kernel holds 72 VGPRs = 7 waves/SIMD) but never more than there are chunks
     const size_t waves_per_cu = nq >= 8 ? 16 : 24;
@@ -318,7 +335,7 @@ static innr_status knn_exact_range(innr_batch* b, int metric, const float* dQ, s
     // one group of 8 queries: all the 8-query groups go into ONE launch (blockIdx.y), within 256 MB of list space.
     // Large corpora keep one group per launch (each launch streams HBM once and fills the chip by itself).
     size_t max_groups = 1;
-    if (b->ldN * b->D * sizeof(float) <= (size_t)128 << 20)
+    if (cols * b->D * sizeof(float) <= (size_t)128 << 20)
         max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * QBMAX * cap * sizeof(uint64_t)));
     max_groups = std::min<size_t>(max_groups, 65535);
     const bool l2 = metric == INNR_METRIC_L2SQ;
@@ -392,7 +409,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
 
 template <int KIND, int MODE>
 static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt, const float* invn, const float* invq,
-                               float* dump, size_t ld_dump) {
+                               float* dump, size_t ld_dump, const uint32_t* seed = nullptr) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
@@ -402,6 +419,8 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     INNR_TRY(c->gthr.ensure(gbytes));
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
+    if (seed)  // initial chip-wide bounds (see seed_thresholds_kernel): valid lower bounds, the slots start empty as usual
+        INNR_HIP_CHECK(hipMemcpyAsync(gslots + p.Qpad * p.KP, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
 #define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
     gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
@@ -490,14 +509,6 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
         INNR_HIP_CHECK(hipGetLastError());
     }
 
-    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0)));
-    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0)));
-    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0)));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-
-    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
-                        (uint32_t)Q));
 
     // dot / cosine: |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum.
     // L2: approx = C - (|v|^2 - 2 q.v + |q|^2) assembled from the MFMA dot (<= (2D+8) u |q||v|, doubled), the squared
@@ -506,6 +517,37 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     // so |(C - approx) - exact| <= (6D+40) u C with room to spare.
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
     const float err_scale = l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm);
+
+    // threshold seeding from the exact top-KP of a corpus prefix (seed_thresholds_kernel)
+    const uint32_t* seed = nullptr;
+    constexpr size_t kSeedN = 2048;
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
+        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, p.KP, c->seed_idx.as<uint64_t>(),
+                                 c->seed_score.as<float>(), ScanExt(), kSeedN));
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
+        seed_thresholds_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(
+            c->seed_score.as<float>(), (uint32_t)Q, p.KP, l2 ? 2 : (cos ? 1 : 0), err_scale, c->q_norm.as<float>(), Cj, sd,
+            (uint32_t)p.Qpad);
+        INNR_HIP_CHECK(hipGetLastError());
+        seed = sd;
+        // the exact engine used the shared list / selection workspace: size it for the GEMM pass again
+        INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+        INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
+        INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
+    }
+
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
+    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
+    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
+                        (uint32_t)Q));
+
 #define INNR_RESCORE(METV, RKV)                                                                                     \
     rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,          \
                                                                  c->q_norm.as<float>(), Cj, c->sel.as<uint64_t>(),  \
@@ -606,7 +648,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc};
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)

@@ -246,7 +246,13 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     for (int kp = 0; kp < kBK / 2; kp += 2) use_after<0>(breg[kp], breg[kp + 1]);
     __syncthreads();  // stages 0 and 1 visible to every wave
 
-    uint32_t tg_next[2] = {0u, 0u};  // chip-wide thresholds of this lane's two queries, refreshed once per tile
+    // chip-wide thresholds of this lane's two queries: read here (they may be seeded, see seed_thresholds_kernel) and
+    // refreshed at the end of every tile's epilogue
+    uint32_t tg_next[2] = {0u, 0u};
+    if (MODE == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], &gthr[q0 + 64 * w + 2 * (lane & 31) + ct]);
+    }
     float iq_lane[2] = {1.0f, 1.0f};  // per-query epilogue constant: COS 1/||q||; U8 offset * sum(q); L2 C_j - |q_j|^2
     if (COS || U8 || L2K) {
         iq_lane[0] = invq[q0 + 64 * w + 2 * (lane & 31) + 0];
@@ -329,6 +335,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
 
 #ifdef INNR_GEMM_PROBE_NOEPI  // tools/gemm_probe.hip: K-loop only (accumulators keep running, results meaningless)
         if (false) {
+#elif defined(INNR_GEMM_PROBE_SKIPEPI)  // same code as the product kernel, epilogue never taken (dump == nullptr at run time)
+        if (ks + 1 == nk && dump != nullptr) {
 #else
         if (ks + 1 == nk) {
 #endif
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                 // Threshold of each of this lane's two queries: the better of the list's own (KP-th best it holds)
                 // and the chip-wide bound gthr[q] (topk_dev.h, global threshold slots).
                 uint32_t thr[2];
-                if (tile != t0) use_after<10>(tg_next[0], tg_next[1]);  // loaded a whole tile ago; wave-uniform branch
+                use_after<10>(tg_next[0], tg_next[1]);  // requested a whole tile ago (or before the first K-step)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const uint32_t tl = __hip_atomic_load(&s.thr[64 * w + 2 * C + ct], __ATOMIC_RELAXED,
@@ -407,12 +415,22 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                     const bool nonneg_thr = (thr[ct] & 0x80000000u) != 0;  // ord of a non-negative float
                     hit[ct] = !nonneg_thr || best[ct] >= (int32_t)(thr[ct] & 0x7fffffffu);
                 }
+#ifdef INNR_GEMM_PROBE_SKIPHIT  // tools/gemm_probe.hip: thresholds + fast reject only, never the append path
+                if (__any(hit[0] || hit[1]) && dump != nullptr) {
+#else
                 if (__any(hit[0] || hit[1])) {
+#endif
+#ifdef INNR_GEMM_PROBE_COUNT  // tools/gemm_probe.hip: how often the append path runs and how much it appends
+                    if (lane == 0) atomicAdd(errflag + 8, 1u);
+                    atomicAdd(errflag + 9, (uint32_t)hit[0] + (uint32_t)hit[1]);
+                    const long long t_hit0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const int ql = 64 * w + 2 * C + ct;
                         uint64_t* lq = my_lists + (size_t)ql * cap;
                         if (hit[ct]) {
+                            bool admitted = false;
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -420,10 +438,15 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                                     const uint32_t o = f32_ord(acc[rt][ct][g]);
                                     const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
                                     if (o >= thr[ct] && i < N) {
+                                        admitted = true;
+#ifdef INNR_GEMM_PROBE_COUNT
+                                        atomicAdd(errflag + 10, 1u);
+#endif
                                         cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
-                                        gthr_offer(gslots + (q0 + ql) * (size_t)KP, gthr + q0 + ql, KP, o, (uint32_t)i);
+                                        gthr_raise(gslots + (q0 + ql) * (size_t)KP, KP, o, (uint32_t)i);
                                     }
                                 }
+                            if (admitted) gthr_publish(gslots + (q0 + ql) * (size_t)KP, gthr + q0 + ql, KP);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -446,6 +469,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+#ifdef INNR_GEMM_PROBE_COUNT
+                    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 12), (unsigned long long)(__builtin_readcyclecounter() - t_hit0));
+#endif
                 }
             }
 #pragma unroll
@@ -651,6 +677,29 @@ __global__ void rerank_prepare_kernel(const uint64_t* __restrict__ cand, uint32_
         v = cand_make(0u, (uint32_t)i);
     }
     sel[t] = v;
+}
+
+// Threshold seeding. Without it every slice appends its whole first tile (no list has a threshold yet, the chip-wide
+// bound is still 0): 128 x 128 slices = 16 384 appends per query, 94 % of all appends of a C2 launch and ~4 % of its
+// time. The exact engine first finds the KP best of a corpus PREFIX per query; their KP-th exact score, lowered by
+// the approximation error bound E (so that all KP of them are certain to clear it with their APPROXIMATE scores), is a
+// valid chip-wide bound from the first tile on. kind: 0 dot (E = err_scale*|q|), 1 cosine (E = err_scale),
+// 2 squared L2 in the epilogue's score space s = C - dist (E = err_scale*C). seed[j] = 0 ("no bound") when not finite.
+__global__ void seed_thresholds_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
+                                       int kind, float err_scale, const float* __restrict__ qnorm, const float* __restrict__ Cj,
+                                       uint32_t* __restrict__ seed /*[Qpad]*/, uint32_t Qpad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Qpad) return;
+    uint32_t o = 0;
+    if (j < Q) {
+        const float x = kth_scores[(size_t)j * KP + KP - 1];
+        float t;
+        if (kind == 2) t = (Cj[j] - x) - err_scale * Cj[j] * 1.0001f;
+        else if (kind == 1) t = x - err_scale * 1.0001f;
+        else t = x - err_scale * qnorm[j] * 1.0001f;
+        if (t - t == 0.0f) o = f32_ord(t);
+    }
+    seed[j] = o;
 }
 
 // L2 on the GEMM engine: per query C_j = (|q_j| + max|v|)^2 and the epilogue constant C_j - |q_j|^2 (padded queries: 0)

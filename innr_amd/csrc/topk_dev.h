@@ -54,25 +54,26 @@ __device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint3
 // t sits near global rank KP*ln(KP) instead of KP: a 3-4x weaker filter than the ideal one, ~S/4 times
 // stronger than a producer's own. Everything is relaxed agent-scope atomicMax / loads: a stale or lost update
 // only makes the bound weaker, never wrong. slots and gthr are zeroed before every launch (0 = "no bound").
-__device__ __forceinline__ void gthr_offer(uint32_t* slots, uint32_t* gthr_q, uint32_t KP, uint32_t pref,
-                                           uint32_t idx) {
-    uint32_t* sl = slots + (idx & (KP - 1));  // KP is a power of two
-    if (pref > __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        const uint32_t old = __hip_atomic_fetch_max(sl, pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // This candidate raised its class: the certified bound may have moved -> rescan. (Rescanning only when the raised
-        // slot held the published minimum looks equivalent and saves most scans, but two racing raises can leave the
-        // published bound below every slot for good; measured: 113.9 -> 122.5 ms at C2. A tight bound is worth more
-        // than the scans cost.)
-        if (old < pref) {
-            uint32_t mn = 0xffffffffu;
-            for (uint32_t j = 0; j < KP; ++j) {
-                const uint32_t v = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mn = mn < v ? mn : v;
-            }
-            if (mn > __hip_atomic_load(gthr_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+// Two halves, so that the appending loop never waits on memory: gthr_raise is a fire-and-forget atomic max per admitted
+// candidate; gthr_publish, once per (lane, query) that admitted anything in a tile, re-reads the KP slots (independent
+// loads: one round trip) and raises the published bound. (One combined call per candidate -- load the slot, atomic max
+// with return, rescan, load and raise the bound -- put 3-4 dependent L2 round trips on every append: tools/gemm_probe.hip
+// measured 87K cycles per visit of the append path, 5 % of the C2 kernel.)
+__device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_t pref, uint32_t idx) {
+    (void)__hip_atomic_fetch_max(slots + (idx & (KP - 1)), pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // KP = 2^n
+}
+__device__ __forceinline__ void gthr_publish(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP) {
+    uint32_t mn = 0xffffffffu;
+    for (uint32_t j = 0; j < KP; j += 4) {
+        const uint32_t v0 = __hip_atomic_load(slots + j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v1 = __hip_atomic_load(slots + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v2 = __hip_atomic_load(slots + j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t v3 = __hip_atomic_load(slots + j + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t a = v0 < v1 ? v0 : v1, b = v2 < v3 ? v2 : v3;
+        mn = mn < a ? mn : a;
+        mn = mn < b ? mn : b;
     }
+    if (mn) (void)__hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Compact a list of `cnt` (<= 64*R) distinct composites to its best min(cnt, KP), written back sorted

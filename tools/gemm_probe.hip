@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../innr_amd/csrc/common.h"
 #include "../innr_amd/csrc/topk_dev.h"
 #include "../innr_amd/csrc/kernels_prep.h"
@@ -43,6 +44,18 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
     }
+#ifdef INNR_GEMM_PROBE_COUNT
+    {
+        uint32_t h[16];
+        CK(hipMemcpy(h, err, sizeof(h), hipMemcpyDeviceToHost));
+        const double tiles_waves = 4.0 * (double)ntiles * nqt * (WAVES / 4.0);  // (tile, wave) epilogues per launch
+        unsigned long long cyc; memcpy(&cyc, h + 12, 8);
+        printf("cycles inside the append path: %.0f per entry; %.2f ms per wave per launch (s_memtime ticks at 100 MHz? raw %llu)\n",
+               (double)cyc / h[8], (double)cyc / 4 / (4.0 * nqt * ns * WAVES / 4.0) / 1e5, cyc);
+        printf("over 4 launches: append path entered %u times (%.1f %% of %.0f wave-epilogues per launch), %u (lane,query) hits, %u appends (%.1f per query per launch)\n",
+               h[8], 100.0 * h[8] / 4 / tiles_waves, tiles_waves, h[9], h[10], h[10] / 4.0 / Q);
+    }
+#endif
     printf("gemm_filter_kernel %zux%zu x %zu queries: %.2f ms -> %.1f TFLOP/s (%.1f %% of 157.3)\n", N, D, Q, best,
            2.0 * N * D * Q / best / 1e9, 2.0 * N * D * Q / best / 1e9 / 1.573);
     return 0;

@@ -268,12 +268,10 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
         // first group of a step, right after the barrier, exposes LDS latency), 16 MFMAs, then the two B registers the
         // group just consumed are reloaded for the next K-step.
         float4 avs[2][2];
-        // The per-lane part of the fragment address is re-derived from the lane id in every step (two VALU ops behind an
-        // opaque copy): hoisted out of the loop it is one more loop-invariant VGPR, and in the cosine / L2 instantiations
-        // hipcc spilled exactly that one -- a scratch reload + s_waitcnt vmcnt(0) at the top of every K-step, which also
-        // drained the DMA and the query loads in flight (L2: 125.6 ms).
-        int lane_k = lane;
-        asm volatile("" : "+v"(lane_k));
+        // (Re-deriving the per-lane fragment address inside the loop, to spare the one VGPR hipcc spills in the cosine / L2
+        //  instantiations, was tried: it removes the scratch reload at the top of the K-step and is slower all the same --
+        //  dot 114 -> 117 ms, cosine 116 -> 121 ms.)
+        const int lane_k = lane;
         auto read_frags = [&](int grp, int set) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

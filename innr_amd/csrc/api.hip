@@ -1296,14 +1296,13 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
 
 template <int QB>
 static innr_status launch_scan_u8(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, uint32_t nblocks,
-                                  uint32_t KP, uint32_t cap, uint32_t cps) {
+                                  uint32_t KP, uint32_t cap, uint32_t cps, uint32_t groups = 1) {
     innr_ctx* c = b->ctx;
     const float a255 = b->alpha / 255.0f;  // scalar.rs:299 (params.alpha / 255.0), f32
 #define INNR_U8_LAUNCH(RR)                                                                                          \
-    scan_u8_filter_kernel<QB, RR><<<nblocks, 256, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->N, (uint32_t)b->D, dQ, ldq, \
-                                                                  qsum, a255, b->offset, c->lists.as<uint64_t>(),     \
-                                                                  c->counts.as<uint32_t>(), QB, KP, cps,              \
-                                                                  c->flags.as<uint32_t>())
+    scan_u8_filter_kernel<QB, RR><<<dim3(nblocks, groups), 256, 0, c->stream>>>(                                    \
+        b->C8, b->ldN, (uint32_t)b->N, (uint32_t)b->D, dQ, ldq, qsum, a255, b->offset, c->lists.as<uint64_t>(),      \
+        c->counts.as<uint32_t>(), QB * groups, KP, cps, c->flags.as<uint32_t>())
     switch (cap) {
         case 384: INNR_U8_LAUNCH(6); break;
         case 768: INNR_U8_LAUNCH(12); break;
@@ -1325,22 +1324,29 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
     nslots = round_up(nslots, 4);
     const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
     const uint32_t nblocks = (uint32_t)(nslots / 4);
-    INNR_TRY(c->lists.ensure(nslots * 4 * cap * sizeof(uint64_t)));
-    INNR_TRY(c->counts.ensure(nslots * 4 * sizeof(uint32_t)));
+    // a code corpus that stays in the Infinity Cache: all 4-query groups in one launch (see knn_exact_range)
+    size_t max_groups = 1;
+    if (b->ldN * b->D <= (size_t)128 << 20)
+        max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * 4 * cap * sizeof(uint64_t)));
+    max_groups = std::min<size_t>(max_groups, 65535);
     size_t done = 0;
     while (done < nq) {
         const uint32_t qb = (nq - done) >= 4 ? 4 : 1;
+        const uint32_t groups = qb == 4 ? (uint32_t)std::min<size_t>((nq - done) / 4, max_groups) : 1u;
+        const uint32_t nql = qb * groups;
+        INNR_TRY(c->lists.ensure(nslots * nql * cap * sizeof(uint64_t)));
+        INNR_TRY(c->counts.ensure(nslots * nql * sizeof(uint32_t)));
         const float* q = dQ + (q0 + done) * ldq;
         const float* qs = qsum + q0 + done;
-        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps));
+        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups));
         else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps));
-        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, qb, cap, KP, qb));
-        const uint32_t total = qb * (uint32_t)kout;
-        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, qb, (uint32_t)kout, false,
+        INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
+        const uint32_t total = nql * (uint32_t)kout;
+        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, nql, (uint32_t)kout, false,
                                                                         b->index_base, d_out_idx + (q0 + done) * kout,
                                                                         d_out_score + (q0 + done) * kout);
         INNR_HIP_CHECK(hipGetLastError());
-        done += qb;
+        done += nql;
     }
     return INNR_OK;
 }

@@ -282,10 +282,15 @@ __global__ __launch_bounds__(256) void scan_u8_filter_kernel(const uint8_t* __re
         s_thr[w][lane] = 0;
     }
     __builtin_amdgcn_wave_barrier();
+    // blockIdx.y = query group (QB consecutive queries each), as in scan_filter_kernel: small corpora put all their
+    // groups into one launch; lists / counts are indexed [slot][query of the launch] (qstride = queries in the launch)
+    const uint32_t qoff = blockIdx.y * QB;
+    Qm += (size_t)qoff * ldq;
+    qsum += qoff;
     const size_t nchunks = ldN / kU8Chunk;
     size_t ch0 = slot * chunks_per_slot, ch1 = ch0 + chunks_per_slot;
     if (ch1 > nchunks) ch1 = nchunks;
-    uint64_t* my_lists = lists + slot * (size_t)qstride * cap;
+    uint64_t* my_lists = lists + (slot * (size_t)qstride + qoff) * cap;
     for (size_t ch = ch0; ch < ch1; ++ch) {
         const size_t col = ch * kU8Chunk + (size_t)lane * 16;
         float acc[QB][16];
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void scan_u8_filter_kernel(const uint8_t* __re
             uint32_t t;
             c = wave_compact<R>(my_lists + (size_t)j * cap, c, KP, &t);
         }
-        if (lane == 0) counts[slot * qstride + j] = c;
+        if (lane == 0) counts[slot * qstride + qoff + j] = c;
     }
 }
 

@@ -121,6 +121,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("INNR_BENCH_ALL_ON_DEVICE0") == "1":  # rehearsal of the N > 1 path on a one-GPU box
+        local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -129,7 +131,11 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("INNR_BENCH_BACKEND", "nccl")  # "gloo": rehearsal only (ranks sharing one GPU)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from innr_amd import KNN_MFMA, METRIC_COSINE, METRIC_DOT, Context, KnnStats
     from innr_amd import batch as B

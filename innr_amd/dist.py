@@ -153,9 +153,15 @@ class ShardedKnn:
         pad_s = torch.zeros((nq, kin), dtype=torch.float32, device=idx.device)
         pad_i[:, :idx.shape[1]] = idx
         pad_s[:, :sc.shape[1]] = sc
-        all_i = torch.empty((self.world, nq, kin), dtype=torch.int64, device=idx.device)
-        all_s = torch.empty((self.world, nq, kin), dtype=torch.float32, device=idx.device)
-        # one exchange step: all-gather of the per-shard candidates (RCCL over xGMI on GPUs, gloo in CPU tests)
-        self.dist.all_gather(list(all_i.unbind(0)), pad_i.contiguous(), group=self.group)
-        self.dist.all_gather(list(all_s.unbind(0)), pad_s.contiguous(), group=self.group)
+        # one exchange step: all-gather of the per-shard candidates (RCCL over xGMI on GPUs, gloo in CPU tests). A gloo
+        # group with device tensors (a rehearsal of the N > 1 path on a box whose ranks share one GPU) gathers through the
+        # host: Q*k*12 bytes per rank.
+        via_host = idx.is_cuda and self.dist.get_backend(self.group) == "gloo"
+        gdev = torch.device("cpu") if via_host else idx.device
+        all_i = torch.empty((self.world, nq, kin), dtype=torch.int64, device=gdev)
+        all_s = torch.empty((self.world, nq, kin), dtype=torch.float32, device=gdev)
+        self.dist.all_gather(list(all_i.unbind(0)), pad_i.contiguous().to(gdev), group=self.group)
+        self.dist.all_gather(list(all_s.unbind(0)), pad_s.contiguous().to(gdev), group=self.group)
+        if via_host:
+            all_i, all_s = all_i.to(idx.device), all_s.to(idx.device)
         return self.merge(all_i, all_s, kout)

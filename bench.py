@@ -115,6 +115,11 @@ def main() -> None:
     args = ap.parse_args()
 
     import numpy as np
+
+    if not args.no_cpu_baseline and int(os.environ.get("RANK", "0")) == 0:
+        import oracle
+        oracle.lib()  # load (or, on a stale build, re-make) the CPU checker BEFORE this process touches the GPU: no exec after HIP init
+
     import torch
     import torch.distributed as dist
 

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Load (and, if its source is newer, re-make) the CPU oracle now, before any test can have initialised the GPU: a
+    # `make` child started later would be an exec from a HIP-initialised process, which the GPU boxes forbid.
+    import oracle
+    oracle.lib()
 
 
 def _have_gpu() -> bool:

@@ -423,12 +423,13 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                     atomicAdd(errflag + 9, (uint32_t)hit[0] + (uint32_t)hit[1]);
                     const long long t_hit0 = __builtin_readcyclecounter();
 #endif
+                    unsigned long long admitted_by[2] = {0ull, 0ull};  // lanes whose query (2*lane + ct) admitted something
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
                         const int ql = 64 * w + 2 * C + ct;
                         uint64_t* lq = my_lists + (size_t)ql * cap;
+                        bool admitted = false;
                         if (hit[ct]) {
-                            bool admitted = false;
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -444,7 +445,20 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                                         gthr_raise(gslots + (q0 + ql) * (size_t)KP, KP, o, (uint32_t)i);
                                     }
                                 }
-                            if (admitted) gthr_publish(gslots + (q0 + ql) * (size_t)KP, gthr + q0 + ql, KP);
+                        }
+                        admitted_by[ct] = __ballot(admitted);
+                    }
+                    // re-derive the chip-wide bound of every query that admitted something: the whole wave reads the KP
+                    // slots of one query at a time (two lanes hold the same query pair: only the lower half reports)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        unsigned long long m = admitted_by[ct];
+                        m = (m | (m >> 32)) & 0xffffffffull;  // lanes l and l+32 own the same two queries
+                        while (m) {
+                            const int L = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const size_t qg = q0 + 64 * w + 2 * L + ct;
+                            gthr_publish_wave(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();

@@ -62,6 +62,16 @@ __device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint3
 __device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_t pref, uint32_t idx) {
     (void)__hip_atomic_fetch_max(slots + (idx & (KP - 1)), pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // KP = 2^n
 }
+// the same, done by a whole wave for one query (wave-uniform arguments): KP/64 loads per lane instead of KP loads by one
+__device__ __forceinline__ void gthr_publish_wave(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane) {
+    uint32_t mn = 0xffffffffu;
+    for (uint32_t j = lane; j < KP; j += 64) {
+        const uint32_t v = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mn = mn < v ? mn : v;
+    }
+    mn = ~wave_max_u32(~mn);  // min over the wave (idle lanes hold ~0)
+    if (lane == 0 && mn) (void)__hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void gthr_publish(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP) {
     uint32_t mn = 0xffffffffu;
     for (uint32_t j = 0; j < KP; j += 4) {

@@ -373,10 +373,10 @@ struct GemmPlan {
 
 static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t force_waves = 0) {
     GemmPlan p;
-    // 512-query tiles (8 waves) halve the corpus re-reads at equal speed when the epilogue is light (KP = 32: k <= 16;
-    // C2 113.9 vs 113.7 ms). With longer candidate lists the epilogue wants a second resident block to hide behind:
-    // k = 100 measured 126.5 ms on 4-wave blocks vs 130.0 on 8-wave ones (u8 at C3: 600 vs 621 ms).
-    p.waves = (Q > 256 && pick_kp(kout, 16) <= 32) ? 8u : 4u;
+    // 512-query tiles (8 waves, one block per CU) halve the corpus re-reads and are as fast or faster for the f32
+    // kinds (k = 10: 112.0 vs 115.6 ms on 4-wave blocks; k = 100: 116.1 vs 118.2). The u8 kind keeps 4 waves (C3:
+    // 592.7 vs 604.0 ms): its 2 KiB corpus stage is only two DMA pieces, which eight waves issue four times over.
+    p.waves = (Q > 256 && !b->C8) ? 8u : 4u;
     if (const char* e = getenv("INNR_GEMM_WAVES")) p.waves = atoi(e) == 8 ? 8u : 4u;
     if (force_waves) p.waves = force_waves;
     const size_t bq = 64 * p.waves;

@@ -98,3 +98,29 @@ def test_random_u8_and_maxsim(seed):
         for engine in (innr_amd.KNN_EXACT, innr_amd.KNN_AUTO):
             idx, sc = dc.topk(q, k, cosine=cosine, engine=engine)
             assert idx.tolist() == order.tolist() and bits_equal(sc, want[order]), (seed, cosine, engine)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_large_mfma_equals_exact_engine(seed):
+    """Larger draws (seeded thresholds, 8-wave tiles, many slices): the GEMM engine against the bit-exact engine, which
+    the smaller draws above pin to the oracle."""
+    import innr_amd
+    from innr_amd import batch as B
+    rng = np.random.default_rng(3000 + seed)
+    n = int(rng.integers(70_000, 400_000))
+    dim = int(rng.choice([24, 64, 100, 128, 200, 256]))
+    nq = int(rng.integers(200, 700))
+    k = int(rng.choice([1, 5, 10, 16, 17, 40, 100]))
+    vb = B.VerticalBatch.generate(n, dim, seed=int(rng.integers(0, 1 << 30)))
+    qs = rng.uniform(-1, 1, size=(nq, dim)).astype(np.float32)
+    if seed % 2:
+        qs[: nq // 8] = np.ascontiguousarray(vb.data()[:, rng.integers(0, n, size=nq // 8)].T)  # queries that are corpus rows
+    sub = rng.choice(nq, size=12, replace=False)
+    for fn in (B.batch_knn_dot_multi, B.batch_knn_cosine_multi, B.batch_knn_multi):
+        st = innr_amd.KnnStats()
+        i1, s1 = fn(qs, vb, k, engine=innr_amd.KNN_MFMA, stats=st)
+        i2, s2 = fn(qs[sub], vb, k, engine=innr_amd.KNN_EXACT)
+        assert bits_equal(s1[sub], s2), (seed, fn.__name__)
+        if fn is not B.batch_knn_multi:
+            assert np.array_equal(i1[sub], i2), (seed, fn.__name__)
+        assert st.queries_fallback <= nq // 4

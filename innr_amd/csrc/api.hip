@@ -917,9 +917,13 @@ innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, s
 }
 
 // which engine INNR_KNN_AUTO resolves to for a Q-query call on this batch (introspection, cf. backend.rs:40-67)
+// gemm_filter_kernel addresses its operands as a 64-bit scalar base + a 32-bit per-lane byte offset (up to 7 corpus
+// rows / one query row): corpora or query batches beyond this take the exact engine (same results, by construction)
+static bool gemm_addressable(const innr_batch* b, size_t Q) { return b->ldN < ((size_t)1 << 29) && Q < ((size_t)1 << 28); }
+
 int innr_batch_auto_engine(const innr_batch* b, size_t Q) {
     if (!b) return INNR_KNN_EXACT;
-    return (Q >= 16 && b->N >= 65536) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    return (Q >= 16 && b->N >= 65536 && gemm_addressable(b, Q)) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
 }
 
 size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
@@ -1050,6 +1054,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
+    if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     const float* dQn = nullptr;
@@ -1428,6 +1433,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
+    if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     uint32_t nfallback = 0, kept = pick_kp(kout, 0);
     float gemm_ms = 0.0f;
     if (engine == INNR_KNN_MFMA) {

@@ -55,16 +55,19 @@ constexpr uint32_t kStageBytesA = kBK * kBC * 4;
 // prefetch and compute. The asm form is invisible to that bookkeeping; the K-loop waits for it explicitly
 // (s_waitcnt vmcnt(0) before the barrier that publishes the stage). M0 is saved/restored around the DMA and
 // the SALU->M0->DMA hazard is padded with s_nop 0 inside the statement.
-__device__ __forceinline__ void glds16(const float* g, uint32_t lds_byte_addr_uniform) {
+// Addresses are wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the K-loop advances the bases on
+// the scalar unit and carries one VGPR per stream instead of a 64-bit per-lane pointer.
+__device__ __forceinline__ void glds16(const char* base_uniform, uint32_t lane_off, uint32_t lds_byte_addr_uniform) {
     uint32_t keep;
+    uint64_t base;  // see gload2 for the s_mov_b64
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b64 %1, %3\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
         "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_byte_addr_uniform)
+        : "=&s"(keep), "=&s"(base)
+        : "v"(lane_off), "s"(base_uniform), "s"(lds_byte_addr_uniform)
         : "memory");
 }
 
@@ -97,15 +100,26 @@ template <int N> __device__ __forceinline__ void wait_but_youngest() { asm volat
 // Query-operand load (8 B per lane) and its use-side wait, both inline asm: left to the compiler, the waits for
 // these loop-carried loads come out as vmcnt(1..3) -- it cannot see the DMA ops in between and resolves the loop
 // back-edge conservatively -- which exposes an L2 round trip in every group. dst is valid only after use_after<N>.
-__device__ __forceinline__ void gload2(float2& dst, const float* p) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+__device__ __forceinline__ void gload2(float2& dst, const char* base_uniform, uint32_t lane_off) {
+    // The base goes through an in-asm s_mov_b64: a VALU-written SGPR (v_readlane of a spilled SGPR, v_readfirstlane) read
+    // by a VMEM instruction needs 5 wait states that hipcc's hazard recogniser does not insert in front of inline asm
+    // (seen: the R = 20 instantiations reload spilled bases right before these loads); SALU reads are interlocked.
+    uint64_t base;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1"
+                 : "=v"(dst), "=&s"(base)
+                 : "v"(lane_off), "s"(base_uniform)
+                 : "memory");
 }
 template <int N> __device__ __forceinline__ void use_after(float2& a, float2& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 // agent-coherent dword load (sc1: served by L2, where the atomics that update it execute), same contract as gload2
-__device__ __forceinline__ void gload1_agent(uint32_t& dst, const uint32_t* p) {
-    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
+__device__ __forceinline__ void gload1_agent(uint32_t& dst, const uint32_t* base_uniform, uint32_t lane_off) {
+    uint64_t base;
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dword %0, %2, %1 sc1"
+                 : "=v"(dst), "=&s"(base)
+                 : "v"(lane_off), "s"(base_uniform)
+                 : "memory");
 }
 template <int N> __device__ __forceinline__ void use_after(uint32_t& a, uint32_t& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
@@ -166,64 +180,68 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
 
-    // Per-lane source pointers of this wave's 2 corpus DMA pieces and of its query operands, advanced incrementally
-    // so the K-loop carries no 64-bit multiplies; wave-uniform LDS destinations computed once.
-    const float* pa[2];
-    uint32_t la[2];  // stage-0 destinations; stage k adds k * kStageBytesA
-    // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each): piece (w & 1) from every wave (pa[0] only)
+    // Source addresses of this wave's corpus DMA pieces and query operands: a wave-uniform base, advanced on the scalar
+    // unit, plus a constant per-lane byte offset (< 4 GiB: the host keeps ldN below 2^29 for this engine).
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const char* sa[2];  // bases of the 2 corpus pieces (u8 and 8-wave tiles: sa[0] only)
+    uint32_t la[2];     // stage-0 LDS destinations; stage k adds k * kStageBytesA
+    uint32_t va;        // per-lane offset inside a piece
+    // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each): piece (w & 1) from every wave
+    if (U8) va = (uint32_t)(lane >> 3) * (uint32_t)ldN + (uint32_t)(lane & 7) * 16u;
+    else va = ((uint32_t)(lane >> 5) * (uint32_t)ldN + (uint32_t)(lane & 31) * 4u) * 4u;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (U8) {
-            pa[j] = reinterpret_cast<const float*>(C8 + (size_t)(8 * (w & 1) + (lane >> 3)) * ldN + (size_t)t0 * kBC +
-                                                   (size_t)(lane & 7) * 16);
-            la[j] = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (w & 1));
-        } else if (kGemmWaves == 8) {  // 8 pieces of 2 rows, one per wave (pa[0] only)
-            pa[j] = V + (size_t)(2 * w + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
-            la[j] = lds_addr_uniform(&s.A[0][2 * w][0]);
+            sa[j] = reinterpret_cast<const char*>(C8 + (size_t)(8 * (wu & 1)) * ldN + (size_t)t0 * kBC);
+            la[j] = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (wu & 1));
+        } else if (kGemmWaves == 8) {  // 8 pieces of 2 rows, one per wave
+            sa[j] = reinterpret_cast<const char*>(V + (size_t)(2 * wu) * ldN + (size_t)t0 * kBC);
+            la[j] = lds_addr_uniform(&s.A[0][2 * wu][0]);
         } else {
-            pa[j] = V + (size_t)(4 * w + 2 * j + (lane >> 5)) * ldN + (size_t)t0 * kBC + (size_t)(lane & 31) * 4;
-            la[j] = lds_addr_uniform(&s.A[0][4 * w + 2 * j][0]);
+            sa[j] = reinterpret_cast<const char*>(V + (size_t)(4 * wu + 2 * j) * ldN + (size_t)t0 * kBC);
+            la[j] = lds_addr_uniform(&s.A[0][4 * wu + 2 * j][0]);
         }
     }
-    // B operands: k-pair kp of the K-step the pointer refers to sits at pb + kp * 2 * Qpad
-    const float* pb = Qt + (size_t)(lane >> 5) * Qpad + q0 + 64 * w + 2 * (lane & 31);
-    const size_t b_kp = 2 * Qpad;
-    // pointer strides in floats (pa is a float* also for u8: byte strides are multiples of 4)
-    const size_t a_step = U8 ? (size_t)kBK * ldN / 4 : (size_t)kBK * ldN, q_step = (size_t)kBK * Qpad;
+    // B operands: k-pair kp of the K-step the base refers to sits at sb + kp * b_kp
+    const char* sb = reinterpret_cast<const char*>(Qt + q0 + 64 * wu);
+    const uint32_t vb = ((uint32_t)(lane >> 5) * (uint32_t)Qpad + 2u * (uint32_t)(lane & 31)) * 4u;
+    const size_t b_kp = 2 * Qpad * 4;
+    // base strides in bytes
+    const size_t a_step = (size_t)kBK * ldN * (U8 ? 1 : 4), q_step = (size_t)kBK * Qpad * 4;
     // subtract at a tile change: back to row 0, next tile
 #ifdef INNR_GEMM_PROBE_L2HOT  // tools/gemm_probe.hip: every block re-reads corpus tile 0 (L2-resident operands)
-    const size_t a_wrap = (size_t)(Dpad - kBK) * ldN;
-    pa[0] -= (size_t)t0 * kBC;
-    pa[1] -= (size_t)t0 * kBC;
+    const size_t a_wrap = (size_t)(Dpad - kBK) * ldN * (U8 ? 1 : 4);
+    sa[0] -= (size_t)t0 * kBC * (U8 ? 1 : 4);
+    sa[1] -= (size_t)t0 * kBC * (U8 ? 1 : 4);
 #else
-    const size_t a_wrap = U8 ? ((size_t)(Dpad - kBK) * ldN - kBC) / 4 : (size_t)(Dpad - kBK) * ldN - kBC;
+    const size_t a_wrap = ((size_t)(Dpad - kBK) * ldN - kBC) * (U8 ? 1 : 4);
 #endif
-    const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad;
-    uint32_t pks = 0, bks = 0;  // K-step index (within a tile) that pa / pb refer to
+    const size_t q_wrap = (size_t)(Dpad - kBK) * Qpad * 4;
+    uint32_t pks = 0, bks = 0;  // K-step index (within a tile) that sa / sb refer to
     auto advance = [&]() {
         if (++pks == nk) {
             pks = 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pa[j] -= a_wrap;
+            for (int j = 0; j < 2; ++j) sa[j] -= a_wrap;
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pa[j] += a_step;
+            for (int j = 0; j < 2; ++j) sa[j] += a_step;
         }
     };
     auto advance_b = [&]() {
         if (++bks == nk) {
             bks = 0;
-            pb -= q_wrap;
+            sb -= q_wrap;
         } else {
-            pb += q_step;
+            sb += q_step;
         }
     };
     auto issue_a = [&](uint32_t stage_off) {
         if (U8 || kGemmWaves == 8) {
-            glds16(pa[0], la[0] + stage_off);  // waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
+            glds16(sa[0], va, la[0] + stage_off);  // waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
         } else {
-            glds16(pa[0], la[0] + stage_off);
-            glds16(pa[1], la[1] + stage_off);
+            glds16(sa[0], va, la[0] + stage_off);
+            glds16(sa[1], va, la[1] + stage_off);
         }
     };
     // prologue: corpus K-steps 0 and 1 into stages 0 and 1, query operands of K-step 0 into registers
@@ -238,8 +256,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     for (int kp = 0; kp < kBK / 2; ++kp) breg[kp] = make_float2(0.f, 0.f);
     if (total) {
 #pragma unroll
-        for (int kp = 0; kp < kBK / 2; ++kp) gload2(breg[kp], pb + kp * b_kp);
-        advance_b();  // pb wraps inside the query matrix at every tile change: always a mapped address
+        for (int kp = 0; kp < kBK / 2; ++kp) gload2(breg[kp], sb + kp * b_kp, vb);
+        advance_b();  // sb wraps inside the query matrix at every tile change: always a mapped address
     }
     wait_all();
 #pragma unroll
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     uint32_t tg_next[2] = {0u, 0u};
     if (MODE == 0) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], &gthr[q0 + 64 * w + 2 * (lane & 31) + ct]);
+        for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + ct, 8u * (uint32_t)(lane & 31));
     }
     float iq_lane[2] = {1.0f, 1.0f};  // per-query epilogue constant: COS 1/||q||; U8 offset * sum(q); L2 C_j - |q_j|^2
     if (COS || U8 || L2K) {
@@ -324,8 +342,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt], bb[ct], acc[rt][ct], 0, 0, 0);
             }
 #ifndef INNR_GEMM_PROBE_NODMA_B  // tools/gemm_probe.hip
-            gload2(breg[2 * grp], pb + (2 * grp) * b_kp);
-            gload2(breg[2 * grp + 1], pb + (2 * grp + 1) * b_kp);
+            gload2(breg[2 * grp], sb + (2 * grp) * b_kp, vb);
+            gload2(breg[2 * grp + 1], sb + (2 * grp + 1) * b_kp, vb);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -406,6 +424,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                                 best[ct] = best[ct] > raw ? best[ct] : raw;
                             }
                     }
+                    // keep the scheduler from hoisting all 16 norm loads (64 registers) above the first use: with the
+                    // 128 accumulators live that is what pushed the cosine / L2 instantiations into scratch
+                    if (COS || L2K) __builtin_amdgcn_sched_barrier(0);
                 }
                 bool hit[2];
 #pragma unroll
@@ -494,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                     for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
             if (MODE == 0) {
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], &gthr[q0 + 64 * w + 2 * (lane & 31) + ct]);
+                for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + ct, 8u * (uint32_t)(lane & 31));
             }
             ks = 0;
             ++tile;

@@ -26,10 +26,13 @@ for name in names:
     body = s[i:s.index("s_endpgm", i)].split("\n")
     pairs = set()
     for k, line in enumerate(body):
-        if ";;#ASMSTART" in line and k + 1 < len(body):
-            m = re.match(r"\s*global_load_dwordx2 v\[(\d+):(\d+)\]", body[k + 1])
-            if m:
-                pairs.add((int(m.group(1)), int(m.group(2))))
+        if ";;#ASMSTART" in line:
+            j = k + 1
+            while j < len(body) and ";;#ASMEND" not in body[j]:
+                m = re.match(r"\s*global_load_dwordx2 v\[(\d+):(\d+)\]", body[j])
+                if m:
+                    pairs.add((int(m.group(1)), int(m.group(2))))
+                j += 1
     flat = {r for a, b in pairs for r in range(a, b + 1)}
     bad = []
     for k, line in enumerate(body):
@@ -61,7 +64,7 @@ for name in names:
             if op.startswith("v_lshl_add_u64") and re.search(r"global_load_dwordx2 " + re.escape(dst), nxt):
                 continue
             bad.append(t)
-    short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3>", name)
+    short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3,\4>", name)
     status = "ok" if (len(pairs) == 8 and not bad) else "FAIL"
     print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads  {status}")
     for b in bad[:5]:

@@ -451,10 +451,17 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                         uint64_t* lq = my_lists + (size_t)ql * cap;
                         bool admitted = false;
                         if (hit[ct]) {
+                            // One compare + branch per value on the way past the 64 sites: "not (v < t)" with t the float
+                            // whose order key is thr is a superset of "key(v) >= thr" (it also passes NaNs and -0 vs +0
+                            // ties; thr = 0, "no bound", maps to a NaN and passes everything). The exact key test follows
+                            // inside. The key conversion per site made this scan ~8K cycles per entry -- and a wave in
+                            // here holds up its whole block at the next K-step barrier.
+                            const float thr_f = ord_f32(thr[ct]);
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                                 for (int g = 0; g < 16; ++g) {
+                                    if (acc[rt][ct][g] < thr_f) continue;
                                     const uint32_t o = f32_ord(acc[rt][ct][g]);
                                     const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
                                     if (o >= thr[ct] && i < N) {
@@ -478,8 +485,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                         while (m) {
                             const int L = __builtin_ctzll(m);
                             m &= m - 1;
-                            const size_t qg = q0 + 64 * w + 2 * L + ct;
-                            gthr_publish_wave(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
+                            const size_t qg = q0 + 64 * wu + 2 * L + ct;  // wave-uniform
+                            gthr_publish_scalar(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();

@@ -55,37 +55,42 @@ __device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint3
 // stronger than a producer's own. Everything is relaxed agent-scope atomicMax / loads: a stale or lost update
 // only makes the bound weaker, never wrong. slots and gthr are zeroed before every launch (0 = "no bound").
 // Two halves, so that the appending loop never waits on memory: gthr_raise is a fire-and-forget atomic max per admitted
-// candidate; gthr_publish, once per (lane, query) that admitted anything in a tile, re-reads the KP slots (independent
-// loads: one round trip) and raises the published bound. (One combined call per candidate -- load the slot, atomic max
-// with return, rescan, load and raise the bound -- put 3-4 dependent L2 round trips on every append: tools/gemm_probe.hip
-// measured 87K cycles per visit of the append path, 5 % of the C2 kernel.)
+// candidate; gthr_publish_scalar, once per query that admitted anything in a tile, re-reads the KP slots and raises the
+// published bound. (One combined call per candidate -- load the slot, atomic max with return, rescan, load and raise
+// the bound -- put 3-4 dependent L2 round trips on every append: tools/gemm_probe.hip measured 87K cycles per visit of
+// the append path, 5 % of the C2 kernel.)
 __device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_t pref, uint32_t idx) {
     (void)__hip_atomic_fetch_max(slots + (idx & (KP - 1)), pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // KP = 2^n
 }
-// the same, done by a whole wave for one query (wave-uniform arguments): KP/64 loads per lane instead of KP loads by one
-__device__ __forceinline__ void gthr_publish_wave(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane) {
+// The publish half, through the SCALAR memory path (slots, gthr_q, KP wave-uniform; KP a multiple of 32): s_load ... glc
+// reads L2, where the atomics execute, and is tracked by lgkmcnt. A vector load would have to be waited for with
+// vmcnt(0) -- vmcnt retires in order -- i.e. behind every prefetch the wave has in flight (gemm_filter_kernel: two
+// K-steps of corpus DMA). Same speed as the wave-wide vector version at C2 (the DMA is usually back by then); kept
+// because the append path now holds no vmcnt wait at all.
+// Not ordered against this wave's own gthr_raise atomics (different path to L2): a raise that has not landed yet
+// yields a smaller minimum, i.e. a weaker but still valid bound, and the next publish of that query picks it up.
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void gthr_publish_scalar(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane) {
     uint32_t mn = 0xffffffffu;
-    for (uint32_t j = lane; j < KP; j += 64) {
-        const uint32_t v = __hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mn = mn < v ? mn : v;
+    for (uint32_t j = 0; j < KP; j += 32) {
+        u32x16_t a, b;
+        uint64_t base;  // copied on the scalar unit first: the compiler adds no hazard padding in front of inline asm
+        asm volatile(
+            "s_mov_b64 %2, %3\n\t"
+            "s_load_dwordx16 %0, %2, 0x0 glc\n\t"
+            "s_load_dwordx16 %1, %2, 0x40 glc\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&s"(a), "=&s"(b), "=&s"(base)
+            : "s"(slots + j)
+            : "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mn = mn < a[i] ? mn : a[i];
+            mn = mn < b[i] ? mn : b[i];
+        }
     }
-    mn = ~wave_max_u32(~mn);  // min over the wave (idle lanes hold ~0)
     if (lane == 0 && mn) (void)__hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void gthr_publish(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP) {
-    uint32_t mn = 0xffffffffu;
-    for (uint32_t j = 0; j < KP; j += 4) {
-        const uint32_t v0 = __hip_atomic_load(slots + j + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t v1 = __hip_atomic_load(slots + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t v2 = __hip_atomic_load(slots + j + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t v3 = __hip_atomic_load(slots + j + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t a = v0 < v1 ? v0 : v1, b = v2 < v3 ? v2 : v3;
-        mn = mn < a ? mn : a;
-        mn = mn < b ? mn : b;
-    }
-    if (mn) (void)__hip_atomic_fetch_max(gthr_q, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Compact a list of `cnt` (<= 64*R) distinct composites to its best min(cnt, KP), written back sorted
 // best-first at list[0..keep). Returns keep; *thr_pref = pref of the KP-th best (0 = "no threshold yet"
 // while fewer than KP entries exist). Rank counting: rank(e) = #entries greater than e; entries are

@@ -36,7 +36,8 @@ int main(int argc, char** argv) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9;
     for (int it = 0; it < 4; ++it) {
-        CK(hipMemset(gs, 0, (Qpad * KP + Qpad) * 4));
+        if (!(getenv("PROBE_KEEP") && it > 0)) CK(hipMemset(gs, 0, (Qpad * KP + Qpad) * 4));  // PROBE_KEEP=1: later launches start from the final thresholds (perfect seeding)
+        if (getenv("PROBE_KEEP") && it == 3) CK(hipMemset(err, 0, 4096));  // counters of the last (perfectly seeded) launch only
         hipEventRecord(a);
         gemm_filter_kernel<kGemmDot, PROBE_R, 0, WAVES><<<nqt * ns, 64 * WAVES>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
                                                                        1.0f, lists, counts, KP, err, gs, gs + Qpad * KP, nullptr, 0);

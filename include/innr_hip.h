@@ -226,6 +226,14 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
                                   const uint64_t* d_cand, size_t kc, size_t k, uint64_t* d_out_idx, float* d_out_score,
                                   size_t* out_k);
 
+/* ---- matryoshka prefix (dense.rs:436-462 matryoshka_dot / matryoshka_cosine; examples/matryoshka_search.rs) ------- */
+/* A batch over the first min(prefix_dims, D) dimensions of `parent` (f32 or u8 codes): the leading rows of the
+ * dimension-major corpus, shared, not copied. Every batch entry point works on it (scores, norms, kNN: its cosine uses
+ * the prefix norms, as matryoshka_cosine does); the coarse stage of the two-stage search is innr_batch_knn on the view
+ * with the queries' first prefix_dims values (row stride = prefix_dims), the fine stage innr_batch_rerank on the
+ * parent. The parent must outlive the view; free the view with innr_batch_free. prefix_dims == 0 is INNR_E_BAD_ARG. */
+innr_status innr_batch_prefix_view(innr_batch* parent, size_t prefix_dims, innr_batch** out);
+
 /* ---- multi-GPU merge (range partition + all-gather of per-shard top-k) --------- */
 /* in: G shards x Q queries x kin candidates (device pointers, layout [g][q][kin], global indices);
  * out: best kout per query by (score order of `metric`, index ascending). */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "innr_batch_knn_u8_dev": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
     "innr_quantize_u8": (None, [_vp, _sz, C.c_float, C.c_float, _vp]),
     "innr_batch_quantize_u8": (C.c_int, [_vp, C.c_float, C.c_float, C.POINTER(_vp)]),
+    "innr_batch_prefix_view": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "innr_batch_minmax": (C.c_int, [_vp, _f32p, _f32p, C.POINTER(C.c_int)]),
     "innr_batch_rerank": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp, _szp]),
     "innr_batch_rerank_dev": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _vp, _szp]),

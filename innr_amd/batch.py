@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
@@ -155,7 +156,22 @@ class VerticalBatch:
         """Range-partitioned corpus: indices reported by kNN become base + local index."""
         check(load().innr_batch_set_index_base(self._h, C.c_uint64(base)))
 
+    def prefix(self, prefix_dims: int) -> "VerticalBatch":
+        """The batch restricted to its first min(prefix_dims, dimension) dimensions -- the batch-level form of
+        matryoshka_dot / matryoshka_cosine (dense.rs:436-462). Dimension-major storage makes this a view of the leading
+        rows on the device: nothing is copied. Closing the parent closes its views."""
+        h = C.c_void_p()
+        check(load().innr_batch_prefix_view(self._h, int(prefix_dims), C.byref(h)))
+        v = VerticalBatch(h, self._n, min(int(prefix_dims), self._d), self._ctx)
+        v._parent = self
+        if not hasattr(self, "_views"):
+            self._views = weakref.WeakSet()
+        self._views.add(v)
+        return v
+
     def close(self) -> None:
+        for v in list(getattr(self, "_views", ())):
+            v.close()
         if getattr(self, "_h", None):
             if getattr(self._ctx, "handle", None):  # a closed ctx has already freed its batches
                 load().innr_batch_free(self._h)
@@ -293,6 +309,28 @@ def batch_rerank(queries, batch: VerticalBatch, candidates, k: int, metric: int 
                                    kc, int(k), _vp(idx), _vp(sc), C.byref(out_k)))
     r = int(out_k.value)
     return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
+
+
+def matryoshka_knn(queries, batch: VerticalBatch, prefix_dims: int, k_coarse: int, k: int, metric: int = METRIC_COSINE,
+                   engine: int = KNN_AUTO, coarse: Optional[VerticalBatch] = None):
+    """Matryoshka progressive search (examples/matryoshka_search.rs:49-73) for a batch of queries: coarse top-k_coarse on
+    the first prefix_dims dimensions (matryoshka_cosine / matryoshka_dot, dense.rs:436-462), then the exact score at
+    full dimension for those candidates, best k. `coarse` may hold batch.prefix(prefix_dims) across calls (its norms are
+    cached on the device). Returns (indices uint64 [Q, k'], scores float32 [Q, k'])."""
+    q = _f32(queries)
+    if q.ndim == 1:
+        q = q.reshape(1, -1)
+    if q.shape[1] != batch.dimension():
+        raise InnrPanic(f"assertion `left == right` failed\n  left: {q.shape[1]}\n right: {batch.dimension()}")
+    if k_coarse > 256:
+        raise InnrPanic("k_coarse <= 256 (innr_batch_rerank)")
+    view = coarse if coarse is not None else batch.prefix(prefix_dims)
+    try:
+        idx, _ = knn_multi(metric, np.ascontiguousarray(q[:, :view.dimension()]), view, k_coarse, engine)
+    finally:
+        if coarse is None:
+            view.close()
+    return batch_rerank(q, batch, idx, k, metric)
 
 
 def _knn_single(metric: int, query, batch: VerticalBatch, k: int, engine: int) -> BatchKnnResult:

@@ -144,6 +144,9 @@ struct innr_batch {
     // scalar-quantised corpus (scalar.rs): codes C8[d*ldN + i] instead of V, with the collection's params
     uint8_t* C8 = nullptr;
     float alpha = 1.0f, offset = 0.0f;
+    // innr_batch_prefix_view: V / C8 belong to another batch (never freed here). Rows D..Dpad of a view can hold the
+    // parent's next dimensions instead of zero padding; the GEMM engine (which multiplies all Dpad rows) is then off.
+    bool is_view = false, gemm_ok = true;
 };
 
 namespace innr {
@@ -771,8 +774,8 @@ void innr_batch_free(innr_batch* b) {
         (void)hipSetDevice(b->ctx->device);
         (void)ctx_sync(b->ctx);
     }
-    if (b->V) (void)hipFree(b->V);
-    if (b->C8) (void)hipFree(b->C8);
+    if (b->V && !b->is_view) (void)hipFree(b->V);
+    if (b->C8 && !b->is_view) (void)hipFree(b->C8);
     if (b->norms) (void)hipFree(b->norms);
     if (b->invn) (void)hipFree(b->invn);
     if (b->sqn) (void)hipFree(b->sqn);
@@ -919,7 +922,9 @@ innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, s
 // which engine INNR_KNN_AUTO resolves to for a Q-query call on this batch (introspection, cf. backend.rs:40-67)
 // gemm_filter_kernel addresses its operands as a 64-bit scalar base + a 32-bit per-lane byte offset (up to 7 corpus
 // rows / one query row): corpora or query batches beyond this take the exact engine (same results, by construction)
-static bool gemm_addressable(const innr_batch* b, size_t Q) { return b->ldN < ((size_t)1 << 29) && Q < ((size_t)1 << 28); }
+static bool gemm_addressable(const innr_batch* b, size_t Q) {
+    return b->gemm_ok && b->ldN < ((size_t)1 << 29) && Q < ((size_t)1 << 28);
+}
 
 int innr_batch_auto_engine(const innr_batch* b, size_t Q) {
     if (!b) return INNR_KNN_EXACT;
@@ -1223,6 +1228,32 @@ innr_status innr_batch_quantize_u8(innr_batch* src, float alpha, float offset, i
         }
     }
     b->index_base = src->index_base;
+    *out = b;
+    return INNR_OK;
+}
+
+// dense.rs:436-462 (matryoshka_dot / matryoshka_cosine) at batch level: the first prefix_dims dimensions of a
+// dimension-major corpus ARE its first prefix_dims rows, so the coarse stage of examples/matryoshka_search.rs is a
+// view, not a copy.
+innr_status innr_batch_prefix_view(innr_batch* parent, size_t prefix_dims, innr_batch** out) {
+    if (!parent || !out || prefix_dims == 0) {
+        set_error("innr_batch_prefix_view: null batch/out or prefix_dims == 0");
+        return INNR_E_BAD_ARG;
+    }
+    innr_batch* b = new (std::nothrow) innr_batch();
+    if (!b) return INNR_E_OOM;
+    b->ctx = parent->ctx;
+    b->N = parent->N;
+    b->ldN = parent->ldN;
+    b->D = std::min(prefix_dims, parent->D);  // prefix_len.min(a.len()), dense.rs:437
+    b->Dpad = round_up(b->D ? b->D : 1, 32);
+    b->V = parent->V;
+    b->C8 = parent->C8;
+    b->alpha = parent->alpha;
+    b->offset = parent->offset;
+    b->index_base = parent->index_base;
+    b->is_view = true;
+    b->gemm_ok = parent->gemm_ok && (b->D == parent->D || b->D % 32 == 0);
     *out = b;
     return INNR_OK;
 }

@@ -30,6 +30,23 @@ def l2_distance(a, b) -> float: return float(np.sqrt(np.float32(l2_distance_squa
 def l1_distance(a, b) -> float: return _pair("innr_l1_f32", "l1_distance", a, b)
 
 
+def _prefix(a, b, prefix_len: int):
+    a = np.asarray(a, dtype=np.float32).reshape(-1)
+    b = np.asarray(b, dtype=np.float32).reshape(-1)
+    end = min(int(prefix_len), a.size, b.size)  # prefix_len.min(a.len()).min(b.len()), dense.rs:437,459
+    return a[:end], b[:end]
+
+
+def matryoshka_dot(a, b, prefix_len: int) -> float:
+    """dense.rs:436-440: dot of the first prefix_len dimensions (clamped to the shorter slice: never a length panic)."""
+    return dot(*_prefix(a, b, prefix_len))
+
+
+def matryoshka_cosine(a, b, prefix_len: int) -> float:
+    """dense.rs:458-462: cosine of the first prefix_len dimensions."""
+    return cosine(*_prefix(a, b, prefix_len))
+
+
 class Distance:
     """distance.rs:66-69"""
     def eval(self, a, b) -> float:  # pragma: no cover - interface

@@ -10,6 +10,7 @@ N separate Vec<u8> allocations per call).
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -223,7 +224,21 @@ class QuantizedCorpus:
         r = int(out_k.value)
         return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
 
+    def prefix(self, prefix_dims: int) -> "QuantizedCorpus":
+        """The corpus restricted to the first min(prefix_dims, dim) code dimensions (same params): a view of the leading
+        rows of the dimension-major code matrix, cf. VerticalBatch.prefix. Closing the parent closes its views."""
+        h = C.c_void_p()
+        check(load().innr_batch_prefix_view(self._h, int(prefix_dims), C.byref(h)))
+        v = QuantizedCorpus(h, self._n, min(int(prefix_dims), self._d), self.params, self._ctx)
+        v._parent = self
+        if not hasattr(self, "_views"):
+            self._views = weakref.WeakSet()
+        self._views.add(v)
+        return v
+
     def close(self) -> None:
+        for v in list(getattr(self, "_views", ())):
+            v.close()
         if getattr(self, "_h", None):
             if getattr(self._ctx, "handle", None):
                 load().innr_batch_free(self._h)

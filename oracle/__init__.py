@@ -264,6 +264,18 @@ def dist_l2(a, b): return _pair(lib().orc_dist_l2)(a, b)
 def dist_l1(a, b): return _pair(lib().orc_dist_l1)(a, b)
 
 
+def _matryoshka(fn, a, b, prefix_len):
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+    return float(fn(a.ctypes.data, a.size, b.ctypes.data, b.size, int(prefix_len)))
+
+
+def matryoshka_dot(a, b, prefix_len): return _matryoshka(lib().orc_matryoshka_dot, a, b, prefix_len)
+def matryoshka_cosine(a, b, prefix_len): return _matryoshka(lib().orc_matryoshka_cosine, a, b, prefix_len)
+
+
 def dist_hamming(a, b) -> float:
     x = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1); y = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
     assert x.size == y.size

@@ -590,6 +590,18 @@ float orc_l1_distance_portable(const float* a, const float* b, size_t n) {
 }
 
 /* distance.rs:73-114 */
+/* dense.rs:436-440 / :458-462: the metric on the first min(prefix_len, a.len(), b.len()) dimensions */
+float orc_matryoshka_dot(const float* a, size_t na, const float* b, size_t nb, size_t prefix_len) {
+    size_t end = prefix_len < na ? prefix_len : na;
+    if (nb < end) end = nb;
+    return orc_dot_portable(a, b, end);
+}
+float orc_matryoshka_cosine(const float* a, size_t na, const float* b, size_t nb, size_t prefix_len) {
+    size_t end = prefix_len < na ? prefix_len : na;
+    if (nb < end) end = nb;
+    return orc_cosine_portable(a, b, end);
+}
+
 float orc_dist_cosine(const float* a, const float* b, size_t n) { return 1.0f - orc_cosine_portable(a, b, n); }
 float orc_dist_dot(const float* a, const float* b, size_t n) { return -orc_dot_portable(a, b, n); }
 float orc_dist_l2(const float* a, const float* b, size_t n) { return sqrtf(orc_l2_distance_squared_portable(a, b, n)); }

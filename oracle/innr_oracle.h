@@ -76,6 +76,9 @@ float orc_cosine_portable(const float* a, const float* b, size_t n);            
 float orc_l2_distance_squared_portable(const float* a, const float* b, size_t n);  /* dense.rs:648-675 */
 float orc_l1_distance_portable(const float* a, const float* b, size_t n);          /* dense.rs:550-572 */
 
+float orc_matryoshka_dot(const float* a, size_t na, const float* b, size_t nb, size_t prefix_len);    /* dense.rs:436-440 */
+float orc_matryoshka_cosine(const float* a, size_t na, const float* b, size_t nb, size_t prefix_len); /* dense.rs:458-462 */
+
 /* ---- distance::Distance<f32>::eval (distance.rs:73-114), portable kernels underneath */
 float orc_dist_cosine(const float* a, const float* b, size_t n); /* 1 - cosine */
 float orc_dist_dot(const float* a, const float* b, size_t n);    /* -dot */

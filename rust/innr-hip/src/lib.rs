@@ -67,6 +67,10 @@ pub mod ffi {
         pub fn innr_maxsim_scores(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, out: *mut f32) -> c_int;
         pub fn innr_maxsim_topk(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int,
                                 out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        // two-stage pipelines: exact re-rank of given candidates; matryoshka prefix view (dense.rs:436-462)
+        pub fn innr_batch_rerank(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, cand: *const u64, kc: usize,
+                                 k: usize, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_prefix_view(parent: *mut InnrBatch, prefix_dims: usize, out: *mut *mut InnrBatch) -> c_int;
         // distance.rs / dense.rs portable pairwise functions (host)
         pub fn innr_dot_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_cosine_f32(a: *const f32, b: *const f32, n: usize) -> f32;
@@ -215,6 +219,46 @@ pub mod batch {
             indices: idx[j * out_k..(j + 1) * out_k].iter().map(|&i| i as usize).collect(),
             scores: sc[j * out_k..(j + 1) * out_k].to_vec(),
         }).collect()
+    }
+
+    /// The first `prefix_dims` dimensions of a batch (batch-level matryoshka_dot / matryoshka_cosine, dense.rs:436-462):
+    /// a view of the leading rows of the dimension-major corpus on the device. Borrows the parent, derefs to a batch.
+    pub struct PrefixBatch<'a> { inner: VerticalBatch, _parent: std::marker::PhantomData<&'a VerticalBatch> }
+    impl<'a> std::ops::Deref for PrefixBatch<'a> { type Target = VerticalBatch; fn deref(&self) -> &VerticalBatch { &self.inner } }
+    impl VerticalBatch {
+        pub fn prefix(&self, prefix_dims: usize) -> PrefixBatch<'_> {
+            let mut h = std::ptr::null_mut();
+            check(unsafe { ffi::innr_batch_prefix_view(self.handle(), prefix_dims, &mut h) });
+            PrefixBatch { inner: VerticalBatch { h, num_vectors: self.num_vectors, dimension: prefix_dims.min(self.dimension), host: Default::default() },
+                          _parent: std::marker::PhantomData }
+        }
+    }
+
+    /// Second stage of the two-stage pipelines (scalar.rs:366-368, examples/matryoshka_search.rs:62-69): exact scores of
+    /// `candidates` (kc per query, kc <= 256) in the reference's order, best k per query.
+    pub fn batch_rerank(metric: i32, queries: &[f32], batch: &VerticalBatch, candidates: &[u64], kc: usize, k: usize) -> Vec<BatchKnnResult> {
+        let d = batch.dimension;
+        let q = if d == 0 { 0 } else { queries.len() / d };
+        assert_eq!(candidates.len(), q * kc);
+        let kk = k.min(kc).max(1);
+        let (mut idx, mut sc, mut out_k) = (vec![0u64; q * kk], vec![0f32; q * kk], 0usize);
+        check(unsafe { ffi::innr_batch_rerank(batch.handle(), metric, queries.as_ptr(), q, d, candidates.as_ptr(), kc, k,
+                                              idx.as_mut_ptr(), sc.as_mut_ptr(), &mut out_k) });
+        (0..q).map(|j| collect(idx[j * out_k..(j + 1) * out_k].to_vec(), sc[j * out_k..(j + 1) * out_k].to_vec(), out_k)).collect()
+    }
+
+    /// examples/matryoshka_search.rs:49-73 for Q queries: coarse top-k_coarse on the first prefix_dims dimensions, then
+    /// the exact full-dimension score of those candidates, best k.
+    pub fn matryoshka_knn(metric: i32, queries: &[f32], batch: &VerticalBatch, prefix_dims: usize, k_coarse: usize, k: usize) -> Vec<BatchKnnResult> {
+        let d = batch.dimension;
+        let view = batch.prefix(prefix_dims);
+        let p = view.dimension;
+        let q = if d == 0 { 0 } else { queries.len() / d };
+        let short: Vec<f32> = (0..q).flat_map(|j| queries[j * d..j * d + p].iter().copied()).collect();
+        let coarse = batch_knn_multi(metric, &short, p, &view, k_coarse);
+        let kc = coarse.first().map_or(0, |r| r.indices.len());
+        let cand: Vec<u64> = coarse.iter().flat_map(|r| r.indices.iter().map(|&i| i as u64)).collect();
+        batch_rerank(metric, queries, batch, &cand, kc, k)
     }
 
     fn knn1(metric: i32, query: &[f32], batch: &VerticalBatch, k: usize) -> BatchKnnResult {
@@ -387,6 +431,15 @@ pub mod distance {
     use super::ffi;
 
     pub trait Distance<T> { fn eval(&self, a: &[T], b: &[T]) -> f32; }
+    /// dense.rs:436-440 / :458-462: the metric on the first min(prefix_len, a.len(), b.len()) dimensions
+    #[must_use] pub fn matryoshka_dot(a: &[f32], b: &[f32], prefix_len: usize) -> f32 {
+        let end = prefix_len.min(a.len()).min(b.len());
+        unsafe { ffi::innr_dot_f32(a.as_ptr(), b.as_ptr(), end) }
+    }
+    #[must_use] pub fn matryoshka_cosine(a: &[f32], b: &[f32], prefix_len: usize) -> f32 {
+        let end = prefix_len.min(a.len()).min(b.len());
+        unsafe { ffi::innr_cosine_f32(a.as_ptr(), b.as_ptr(), end) }
+    }
     fn pair(f: unsafe extern "C" fn(*const f32, *const f32, usize) -> f32, a: &[f32], b: &[f32]) -> f32 {
         assert_eq!(a.len(), b.len());
         unsafe { f(a.as_ptr(), b.as_ptr(), a.len()) }

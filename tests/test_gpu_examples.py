@@ -27,3 +27,8 @@ def test_batch_demo_runs(capsys):
 def test_maxsim_colbert_runs(capsys):
     _load("maxsim_colbert").main(n_docs=300, n_doc_tokens=24, n_query_tokens=8, dim=64)
     assert "ranking equals a stable sort" in capsys.readouterr().out
+
+
+def test_matryoshka_search_runs(capsys):
+    _load("matryoshka_search").main(corpus_size=3000, full_dim=96, prefix_dim=32, coarse_k=50, final_k=5, num_queries=3)
+    assert "re-ranked scores are the exact full-dimension cosines" in capsys.readouterr().out

@@ -115,3 +115,29 @@ def test_topk_matches_oracle_on_random_streams(mods):
             a.insert(i, float(v)); b.insert(i, float(v))
             assert a.threshold() == b.threshold()
         assert a.into_sorted() == b.into_sorted()
+
+
+def test_matryoshka_reference_kats(mods):  # src/dense.rs:681-703, 928-1003
+    D, _, _ = mods
+    for impl_dot, impl_cos, full_dot, full_cos in (
+            (D.matryoshka_dot, D.matryoshka_cosine, D.dot, D.cosine),
+            (oracle.matryoshka_dot, oracle.matryoshka_cosine, oracle.dot_portable, oracle.cosine_portable)):
+        a, b = [1.0, 2.0, 3.0, 4.0, 5.0], [5.0, 4.0, 3.0, 2.0, 1.0]
+        for prefix, want in zip((1, 2, 3, 4, 5), (5.0, 13.0, 22.0, 30.0, 35.0)):  # test_matryoshka_dot_equals_prefix_dot
+            assert impl_dot(a, b, prefix) == want == full_dot(a[:prefix], b[:prefix])
+        assert impl_dot([1.0, 0.0, -1.0], [2.0, 3.0, 4.0], 3) == -2.0          # ..._full_prefix_equals_dot
+        assert impl_dot([1.0, 2.0], [3.0, 4.0], 100) == 11.0                    # ..._prefix_longer_than_vec_clips
+        a, b = [1.0, 2.0, 3.0, 4.0], [4.0, 3.0, 2.0, 1.0]
+        for prefix in (1, 2, 3, 4):                                             # test_matryoshka_cosine_equals_prefix_cosine
+            assert impl_cos(a, b, prefix) == full_cos(a[:prefix], b[:prefix])
+        assert abs(impl_cos([1.0, 0.0], [0.0, 1.0], 2)) < 1e-6                  # ..._full_prefix_equals_cosine
+        assert abs(impl_cos([3.0, -99.0, -99.0], [5.0, 1.0, 1.0], 1) - 1.0) < 1e-5  # ..._prefix_one
+        q, d1, d2, d3 = [1.0, 0.5, 0.2, 0.1], [0.9, 0.4, 0.1, 0.05], [0.1, 0.1, 0.1, 0.1], [-0.5, -0.2, 0.0, 0.0]
+        assert full_cos(q, d1) > full_cos(q, d2) > full_cos(q, d3)              # test_matryoshka_ranking_preservation
+        assert impl_cos(q, d1, 2) > impl_cos(q, d2, 2) > impl_cos(q, d3, 2)
+    rng = np.random.default_rng(5)
+    for n, prefix in ((0, 4), (7, 0), (33, 16), (128, 128), (100, 64), (9, 200)):
+        a = rng.normal(size=n).astype(np.float32)
+        b = rng.normal(size=n + 3).astype(np.float32)  # unequal lengths clip, never panic (dense.rs:437)
+        assert D.matryoshka_dot(a, b, prefix) == oracle.matryoshka_dot(a, b, prefix)
+        assert D.matryoshka_cosine(a, b, prefix) == oracle.matryoshka_cosine(a, b, prefix)

@@ -418,16 +418,17 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     uint32_t* counts = c->counts.as<uint32_t>();
     uint32_t* err = c->flags.as<uint32_t>();
     // chip-wide threshold state: [Qpad][KP] slots followed by [Qpad] bounds, zeroed for every launch
-    const size_t gbytes = (p.Qpad * p.KP + p.Qpad) * sizeof(uint32_t);
+    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
+    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
     INNR_TRY(c->gthr.ensure(gbytes));
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
     if (seed)  // initial chip-wide bounds (see seed_thresholds_kernel): valid lower bounds, the slots start empty as usual
-        INNR_HIP_CHECK(hipMemcpyAsync(gslots + p.Qpad * p.KP, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
 #define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
     gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
-        p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + p.Qpad * p.KP, dump,   \
+        p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + nslot, dump,   \
         ld_dump)
     // the 8-wave (512-query) tile exists for the product path only (MODE 0); the layout-dump hook stays on 4 waves
 #define INNR_GEMM_LAUNCH(RR)                                                                                    \

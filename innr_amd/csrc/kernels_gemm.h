@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
-    uint32_t* gslots /*[Qpad][KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
+    uint32_t* gslots /*[Qpad][kSlotMul * KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
@@ -455,7 +455,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                             // whose order key is thr is a superset of "key(v) >= thr" (it also passes NaNs and -0 vs +0
                             // ties; thr = 0, "no bound", maps to a NaN and passes everything). The exact key test follows
                             // inside. The key conversion per site made this scan ~8K cycles per entry -- and a wave in
-                            // here holds up its whole block at the next K-step barrier.
+                            // here holds up its whole block at the next K-step barrier. (Walking the values with a
+                            // runtime loop over a per-wave LDS stage instead -- one copy of the append code, kernel 12.5
+                            // instead of 33 KB -- was tried: 18K cycles per entry instead of 7.5K, +1.2 ms.)
                             const float thr_f = ord_f32(thr[ct]);
 #pragma unroll
                             for (int rt = 0; rt < 4; ++rt)
@@ -470,12 +472,15 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                                         atomicAdd(errflag + 10, 1u);
 #endif
                                         cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
-                                        gthr_raise(gslots + (q0 + ql) * (size_t)KP, KP, o, (uint32_t)i);
+                                        gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
                                     }
                                 }
                         }
                         admitted_by[ct] = __ballot(admitted);
                     }
+#ifdef INNR_GEMM_PROBE_COUNT
+                    const long long t_hit1 = __builtin_readcyclecounter();
+#endif
                     // re-derive the chip-wide bound of every query that admitted something: the whole wave reads the KP
                     // slots of one query at a time (two lanes hold the same query pair: only the lower half reports)
 #pragma unroll
@@ -486,9 +491,17 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
                             const int L = __builtin_ctzll(m);
                             m &= m - 1;
                             const size_t qg = q0 + 64 * wu + 2 * L + ct;  // wave-uniform
-                            gthr_publish_scalar(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
+                            if (kSlotMul == 1) gthr_publish_scalar(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
+                            else gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);  // KP == 16 R - 64 (cand_cap)
                         }
                     }
+#ifdef INNR_GEMM_PROBE_COUNT
+                    const long long t_hit2 = __builtin_readcyclecounter();
+                    if (lane == 0) {
+                        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 14), (unsigned long long)(t_hit1 - t_hit0));
+                        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 16), (unsigned long long)(t_hit2 - t_hit1));
+                    }
+#endif
                     __builtin_amdgcn_wave_barrier();
                     // compact the lists of this wave's queries that are running out of room
                     const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

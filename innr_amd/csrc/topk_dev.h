@@ -47,21 +47,47 @@ __device__ __forceinline__ void cand_append(uint64_t* list, uint32_t* cnt, uint3
 
 // ---- chip-wide threshold ("global threshold slots") ---------------------------------------------------
 // With S producers per query each list's own threshold only knows 1/S of the corpus seen so far, so almost
-// every tile still yields candidates. The producers therefore share, per query, KP monotone slots:
-//   slots[idx % KP] = max pref of any admitted candidate whose corpus index falls in that residue class.
-// Distinct slots were raised by distinct corpus vectors, so t = min over the KP slots certifies "at least KP
+// every tile still yields candidates. The producers therefore share, per query, S = kSlotMul*KP monotone slots:
+//   slots[idx % S] = max pref of any admitted candidate whose corpus index falls in that residue class.
+// Distinct slots were raised by distinct corpus vectors, so t = the KP-th largest slot value certifies "at least KP
 // vectors score >= t": anything below t cannot be in the top KP, whichever producer sees it (ties pass).
-// t sits near global rank KP*ln(KP) instead of KP: a 3-4x weaker filter than the ideal one, ~S/4 times
-// stronger than a producer's own. Everything is relaxed agent-scope atomicMax / loads: a stale or lost update
-// only makes the bound weaker, never wrong. slots and gthr are zeroed before every launch (0 = "no bound").
+// Everything is relaxed agent-scope atomicMax / loads: a stale or lost update only makes the bound weaker, never
+// wrong. slots and gthr are zeroed before every launch (0 = "no bound").
 // Two halves, so that the appending loop never waits on memory: gthr_raise is a fire-and-forget atomic max per admitted
-// candidate; gthr_publish_scalar, once per query that admitted anything in a tile, re-reads the KP slots and raises the
+// candidate; gthr_publish_select, once per query that admitted anything in a tile, re-reads the slots and raises the
 // published bound. (One combined call per candidate -- load the slot, atomic max with return, rescan, load and raise
 // the bound -- put 3-4 dependent L2 round trips on every append: tools/gemm_probe.hip measured 87K cycles per visit of
 // the append path, 5 % of the C2 kernel.)
 __device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_t pref, uint32_t idx) {
     (void)__hip_atomic_fetch_max(slots + (idx & (KP - 1)), pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // KP = 2^n
 }
+// Slots per query = kSlotMul * KP. With exactly KP slots the bound is the MINIMUM of KP bucket maxima, which sits near
+// global rank KP*ln(KP) (coupon collector: every bucket must have been hit); with 4*KP slots the bound is the KP-th
+// LARGEST bucket maximum -- still a certificate of KP distinct vectors -- and sits near rank 1.15*KP.
+#ifndef INNR_SLOT_MUL
+#define INNR_SLOT_MUL 4
+#endif
+constexpr uint32_t kSlotMul = INNR_SLOT_MUL;
+
+// KP-th largest of the S = kSlotMul*KP slot values of one query (wave-uniform arguments), by bisection on the 32 key
+// bits with ballot counts: t = max{x : #(slots >= x) >= KP}; 0 while fewer than KP slots are filled.
+template <int NR>  // NR = S / 64 slot values per lane
+__device__ __forceinline__ void gthr_publish_select(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane) {
+    uint32_t v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = __hip_atomic_load(slots + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t t = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = t | (1u << bit);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cnt += (uint32_t)__popcll(__ballot(v[r] >= cand));
+        if (cnt >= KP) t = cand;
+    }
+    if (lane == 0 && t) (void)__hip_atomic_fetch_max(gthr_q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The publish half, through the SCALAR memory path (slots, gthr_q, KP wave-uniform; KP a multiple of 32): s_load ... glc
 // reads L2, where the atomics execute, and is tracked by lgkmcnt. A vector load would have to be waited for with
 // vmcnt(0) -- vmcnt retires in order -- i.e. behind every prefetch the wave has in flight (gemm_filter_kernel: two

@@ -374,12 +374,14 @@ struct GemmPlan {
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, waves;
 };
 
-static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t force_waves = 0) {
+static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t force_waves = 0, bool dot_kind = false) {
     GemmPlan p;
-    // 512-query tiles (8 waves, one block per CU) halve the corpus re-reads and are as fast or faster for the f32
-    // kinds (k = 10: 112.0 vs 115.6 ms on 4-wave blocks; k = 100: 116.1 vs 118.2). The u8 kind keeps 4 waves (C3:
-    // 592.7 vs 604.0 ms): its 2 KiB corpus stage is only two DMA pieces, which eight waves issue four times over.
-    p.waves = (Q > 256 && !b->C8) ? 8u : 4u;
+    // 512-query tiles (8 waves, one block per CU) halve the corpus re-reads (68 vs 123 GB of L2-miss traffic at C2) at
+    // the same speed for the dot kind (106.9 vs 106.7 ms). The other kinds keep 4 waves, two blocks per CU: a wave
+    // that stalls in its epilogue (norm loads, the append path) then holds up only its own block -- cosine 107.0 vs
+    // 107.9 ms, L2 107.7 vs 108.3, u8 at C3 571 vs 582 (its 2 KiB corpus stage is only two DMA pieces, which eight
+    // waves issue four times over).
+    p.waves = (Q > 256 && dot_kind && !b->C8) ? 8u : 4u;
     if (const char* e = getenv("INNR_GEMM_WAVES")) p.waves = atoi(e) == 8 ? 8u : 4u;
     if (force_waves) p.waves = force_waves;
     const size_t bq = 64 * p.waves;
@@ -492,7 +494,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
                             float* gemm_ms) {
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
-    const GemmPlan p = plan_gemm(b, Q, kout);
+    const GemmPlan p = plan_gemm(b, Q, kout, 0, !cos && !l2);
     INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
     if (cos) INNR_TRY(ensure_invnorms(b));
     if (l2) INNR_TRY(ensure_sqnorms(b));

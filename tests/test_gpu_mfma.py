@@ -259,3 +259,15 @@ def test_knn_mfma_near_ties_around_the_cut(B, innr, cluster):
             assert st.queries_fallback >= len(qs) // 2, (metric, st.queries_fallback)  # the cut is inside the cluster
         if cluster < 32 and metric == "dot":
             assert st.queries_fallback <= 2, st.queries_fallback
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves, monkeypatch):
+    # plan_gemm picks 8-wave (512-query) tiles for dot and 4-wave tiles for cosine / L2; INNR_GEMM_WAVES forces either,
+    # so every (kind, block shape) instantiation stays under test
+    monkeypatch.setenv("INNR_GEMM_WAVES", waves)
+    rows, data = _corpus(70_000, 64, 31, uniform=True)
+    vb = None
+    for metric in ("dot", "cos", "l2"):
+        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(600, 64, 777, uniform=True), 10,
+                        innr.KNN_MFMA)

@@ -50,7 +50,11 @@ typedef int innr_status;
 #define INNR_KNN_EXACT 1 /* bit-exact VALU scan in the reference's arithmetic order (HBM-bound) */
 #define INNR_KNN_MFMA 2  /* f32 MFMA GEMM + fused top-k filter + exact re-score (MFMA-bound) */
 
-#define INNR_MAX_K 240 /* largest k one call supports (device candidate lists hold k + margin <= 256) */
+#define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). innr_batch_knn[_dev] and
+                        * innr_batch_knn_u8[_dev] accept any k: beyond INNR_MAX_K they compute all N scores and sort them on
+                        * the device, one query at a time (the reference's own algorithm, batch.rs:754-763), and so does
+                        * innr_maxsim_topk[_multi] with its document scores. The L2 variants (filtered / reordered /
+                        * adaptive) and innr_batch_rerank* return INNR_E_UNSUPPORTED beyond it. */
 
 typedef struct innr_ctx innr_ctx;     /* one GPU: device id, stream, workspace. One per process/GPU. */
 typedef struct innr_batch innr_batch; /* device-resident VerticalBatch (PDX, dimension-major) + cached norms */

@@ -90,6 +90,9 @@ struct innr_ctx {
     DevBuf seed_idx;   // threshold seeding: exact top-KP of a corpus prefix (indices unused, scores -> bounds)
     DevBuf seed_score;
     DevBuf misc;
+    DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
+    DevBuf sort_keys;  // [2][N] composites: unsorted, sorted
+    DevBuf sort_tmp;   // radix sort scratch
 };
 
 namespace innr {
@@ -654,7 +657,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score};
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)
@@ -1032,6 +1035,68 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
     return INNR_OK;
 }
 
+}  // extern "C"
+
+namespace innr {  // sort_full.hip
+hipError_t full_sort_scratch_bytes(size_t n, size_t* bytes);
+hipError_t full_sort_scores(const float* scores, size_t n, bool smaller_is_better, uint64_t* keys, uint64_t* sorted,
+                            void* scratch, size_t scratch_bytes, hipStream_t stream);
+}  // namespace innr
+
+// k > INNR_MAX_K: more results than a candidate list holds. The reference's own algorithm, on the device: all N
+// scores of one query (scan_scores_kernel: the reference-order arithmetic the exact engine uses), a full sort of
+// (score, index) composites, truncate (batch.rs:754-763, 790-799, scalar.rs:383-392; for batch_knn's TopK,
+// batch.rs:398-409, the same k smallest in the same order up to ties at equal distances). One query at a time: the
+// path is for the rare "give me everything, ranked" call, 10M vectors sort in a few milliseconds.
+// metric < 0: u8 codes (aux = per-query sum(q)); cosine: aux = per-query norms.
+static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, size_t D, const float* aux, size_t Q,
+                                 size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+    innr_ctx* c = b->ctx;
+    const size_t ldq = round_up(D ? D : 1, 4), N = b->N;
+    size_t tmp_bytes = 0;
+    INNR_HIP_CHECK(full_sort_scratch_bytes(N, &tmp_bytes));
+    INNR_TRY(c->q_one.ensure(ldq * sizeof(float)));
+    INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
+    INNR_TRY(c->sort_keys.ensure(2 * N * sizeof(uint64_t)));
+    INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+    INNR_HIP_CHECK(hipMemsetAsync(c->q_one.p, 0, ldq * sizeof(float), c->stream));
+    if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
+    const bool smaller = metric == INNR_METRIC_L2SQ;
+    const float* dq = c->q_one.as<float>();
+    float* ds = c->scores.as<float>();
+    uint64_t* keys = c->sort_keys.as<uint64_t>();
+    for (size_t q = 0; q < Q; ++q) {
+        if (D) INNR_HIP_CHECK(hipMemcpyAsync(c->q_one.p, dQ + q * D, D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        if (metric < 0) {
+            const size_t nchunks = b->ldN / kU8Chunk;
+            const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+            scan_u8_scores_kernel<1><<<blocks, 256, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)D, dq, ldq, aux + q,
+                                                                    b->alpha / 255.0f, b->offset, ds, b->ldN);
+        } else {
+            const size_t nchunks = b->ldN / kScanChunk;
+            const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+            if (metric == INNR_METRIC_DOT)
+                scan_scores_kernel<1, false, false><<<blocks, kScanThreads, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, dq, ldq,
+                                                                                           nullptr, nullptr, ds, b->ldN);
+            else if (metric == INNR_METRIC_L2SQ)
+                scan_scores_kernel<1, true, false><<<blocks, kScanThreads, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, dq, ldq,
+                                                                                          nullptr, nullptr, ds, b->ldN);
+            else
+                scan_scores_kernel<1, false, true><<<blocks, kScanThreads, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, dq, ldq,
+                                                                                          b->norms, aux + q, ds, b->ldN);
+        }
+        INNR_HIP_CHECK(hipGetLastError());
+        INNR_HIP_CHECK(full_sort_scores(ds, N, smaller, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream));
+        emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(keys + N, 0, 1, (uint32_t)kout, smaller,
+                                                                               b->index_base, d_out_idx + q * kout,
+                                                                               d_out_score + q * kout);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    return INNR_OK;
+}
+
+extern "C" {
+
 // ---- kNN -----------------------------------------------------------------------------------------------
 innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D, size_t k,
                                int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
@@ -1052,10 +1117,6 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     *out_k = 0;
     if (b->N == 0 || k == 0 || Q == 0) return INNR_OK;  // batch.rs:388-393, 745-750
     const size_t kout = std::min(k, b->N);              // batch.rs:395, 752
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
@@ -1063,6 +1124,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
     if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
+    if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     const float* dQn = nullptr;
@@ -1078,6 +1140,9 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     float gemm_ms = 0.0f;
     if (engine == INNR_KNN_MFMA) {
         INNR_TRY(knn_mfma(b, metric, d_queries, Q, kout, dQn, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
+    } else if (kout > INNR_MAX_K) {
+        INNR_TRY(knn_full_sort(b, metric, d_queries, D, dQn, Q, kout, d_out_idx, d_out_score));
+        kept = (uint32_t)b->N;
     } else {
         INNR_TRY(knn_exact_range(b, metric, d_queries, D, dQn, 0, Q, kout, d_out_idx, d_out_score));
         kept = pick_kp(kout, 0);
@@ -1452,10 +1517,6 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_TRY(u8_check(b, D));
     if (Q == 0) return INNR_OK;
     const size_t kout = std::min(k, b->N);  // scalar.rs:381
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
     INNR_TRY(bind_device(c));
@@ -1468,9 +1529,12 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
     if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
-    uint32_t nfallback = 0, kept = pick_kp(kout, 0);
+    if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;
+    uint32_t nfallback = 0, kept = kout > INNR_MAX_K ? (uint32_t)b->N : pick_kp(kout, 0);
     float gemm_ms = 0.0f;
-    if (engine == INNR_KNN_MFMA) {
+    if (kout > INNR_MAX_K) {
+        INNR_TRY(knn_full_sort(b, -1, d_queries, D, qsum, Q, kout, d_out_idx, d_out_score));
+    } else if (engine == INNR_KNN_MFMA) {
         INNR_TRY(knn_u8_mfma(b, d_queries, Q, kout, qsum, qnorm, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
     } else {
         INNR_TRY(knn_u8_exact_range(b, d_queries, D, qsum, 0, Q, kout, d_out_idx, d_out_score));
@@ -1872,6 +1936,21 @@ static innr_status maxsim_topk_exact(innr_docs* d, int cosine, const float* qtok
     innr_ctx* c = d->ctx;
     INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, d->dim));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    if (kout > INNR_MAX_K) {  // more results than a candidate list holds: sort all document scores (cf. knn_full_sort)
+        size_t tmp_bytes = 0;
+        INNR_HIP_CHECK(full_sort_scratch_bytes(d->ndocs, &tmp_bytes));
+        INNR_TRY(c->sort_keys.ensure(2 * d->ndocs * sizeof(uint64_t)));
+        INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        uint64_t* keys = c->sort_keys.as<uint64_t>();
+        INNR_HIP_CHECK(full_sort_scores(c->scores.as<float>(), d->ndocs, false, keys, keys + d->ndocs, c->sort_tmp.p, tmp_bytes,
+                                        c->stream));
+        emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(keys + d->ndocs, 0, 1, (uint32_t)kout, false,
+                                                                               d->index_base, c->out_idx.as<uint64_t>() + out_off,
+                                                                               c->out_score.as<float>() + out_off);
+        INNR_HIP_CHECK(hipGetLastError());
+        *kp_out = (uint32_t)d->ndocs;
+        return INNR_OK;
+    }
     const uint32_t KP = pick_kp(kout, 0);
     *kp_out = KP;
     INNR_TRY(maxsim_select(d, KP, c->scores.as<float>()));
@@ -1895,13 +1974,9 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
         return INNR_E_DIM_MISMATCH;
     }
     if (d->ndocs == 0 || k == 0) return INNR_OK;
-    const size_t kout = std::min(k, d->ndocs);
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
+    const size_t kout = std::min(k, d->ndocs);  // beyond INNR_MAX_K: the exact engine sorts all document scores
     if (!out_doc || !out_score) return INNR_E_BAD_ARG;
-    const bool eligible = maxsim_mfma_eligible(d, Tq) && pick_kp(kout, 16) <= 256;
+    const bool eligible = maxsim_mfma_eligible(d, Tq) && kout <= INNR_MAX_K && pick_kp(kout, 16) <= 256;
     if (engine == INNR_KNN_MFMA && !eligible) {
         set_error("maxsim MFMA engine needs T > 16, dim %% 8 == 0, 8 <= dim <= 512, a non-empty query and k <= 240");
         return INNR_E_UNSUPPORTED;
@@ -1971,10 +2046,6 @@ innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks,
     }
     if (d->ndocs == 0 || k == 0 || Q == 0) return INNR_OK;
     const size_t kout = std::min(k, d->ndocs);
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
     if (!out_doc || !out_score) return INNR_E_BAD_ARG;
     std::vector<size_t> Tqs(Q);
     size_t tq_max = 0, tq_min = Tq_stride;
@@ -1983,7 +2054,7 @@ innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks,
         tq_max = std::max(tq_max, Tqs[i]);
         tq_min = std::min(tq_min, Tqs[i]);
     }
-    const bool eligible = tq_min > 0 && maxsim_mfma_eligible(d, tq_min) && pick_kp(kout, 16) <= 256;
+    const bool eligible = tq_min > 0 && maxsim_mfma_eligible(d, tq_min) && kout <= INNR_MAX_K && pick_kp(kout, 16) <= 256;
     if (engine == INNR_KNN_MFMA && !eligible) {
         set_error("maxsim MFMA engine needs T > 16, dim %% 8 == 0, 8 <= dim <= 512, non-empty queries and k <= 240");
         return INNR_E_UNSUPPORTED;

@@ -204,10 +204,12 @@ def test_knn_exact_uniform_data(B, innr, metric):
     _check_knn(B, innr, metric, rows, data, _queries(24, 96, 8, uniform=True), 20, innr.KNN_EXACT)
 
 
-def test_knn_k_limit_is_loud(B, innr):
+def test_knn_k_limit_is_loud_where_it_remains(B, innr):
+    # batch_knn / _dot / _cosine take any k (full-sort path beyond INNR_MAX_K); the L2 variants keep the limit and say so
     vb = B.VerticalBatch.generate(1000, 8, 0)
+    assert len(B.batch_knn_dot(np.zeros(8, np.float32), vb, 241).indices) == 241
     with pytest.raises(innr.InnrError):
-        B.batch_knn_dot(np.zeros(8, np.float32), vb, 241)
+        B.batch_knn_filtered(np.zeros(8, np.float32), vb, 241, lambda i: True)
 
 
 def test_knn_ties_resolve_to_lower_index(B, innr):
@@ -300,3 +302,24 @@ def test_save_load_roundtrip(B, tmp_path):
     import innr_amd
     with pytest.raises(innr_amd.InnrPanic):
         B.VerticalBatch.load(path)
+
+
+# ------------------------------------------------------------------------------- k beyond the candidate lists
+@pytest.mark.parametrize("n,dim,nq,k", [(1000, 16, 3, 241), (5000, 33, 2, 5000), (5000, 33, 2, 10**9), (20_000, 64, 2, 1500)])
+def test_knn_large_k_full_sort(B, innr, n, dim, nq, k):
+    # k > INNR_MAX_K (240): all scores + a full device sort, the reference's own algorithm (batch.rs:754-763); k = N is
+    # the complete ranking, k > N clamps to N (batch.rs:752). Whatever engine the caller names, the result is exact.
+    rows, data = _corpus(n, dim, 19)
+    vb = None
+    for metric in ("dot", "cos", "l2"):
+        for engine in (innr.KNN_AUTO, innr.KNN_MFMA):
+            vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(nq, dim, 4242), k, engine)
+
+
+def test_knn_large_k_ties_keep_index_order(B, innr):
+    # duplicates everywhere: the full ranking must list equal scores by ascending index (stable sort, batch.rs:757)
+    base = oracle.generate_uniform(50, 24, 3)
+    rows = np.concatenate([base] * 20)
+    data = oracle.from_rows(rows)
+    _check_knn(B, innr, "dot", rows, data, _queries(2, 24, 7, uniform=True), 1000, innr.KNN_AUTO)
+    _check_knn(B, innr, "cos", rows, data, _queries(2, 24, 7, uniform=True), 600, innr.KNN_AUTO)

@@ -63,7 +63,7 @@ def test_maxsim_doc_len_and_empties(M):
         dc.scores(np.ones((2, 31), np.float32))
 
 
-@pytest.mark.parametrize("ndocs,k", [(10, 3), (2000, 10), (5000, 100), (700, 240)])
+@pytest.mark.parametrize("ndocs,k", [(10, 3), (2000, 10), (5000, 100), (700, 240), (700, 241), (3000, 3000), (900, 10**7)])
 def test_maxsim_topk_equals_stable_sort(M, ndocs, k):
     T, dim, Tq = 16, 64, 8
     toks = _tokens(ndocs, T, dim, 12)

@@ -54,7 +54,7 @@ def test_u8_layout_generator_and_scores_bit_exact(S, n, dim):
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(4, 3, 1, 2), (300, 16, 3, 10), (5000, 64, 9, 33), (20_000, 128, 5, 100),
-                                        (3000, 20, 2, 240)])
+                                        (3000, 20, 2, 240), (3000, 20, 2, 241), (3000, 20, 2, 3000), (700, 33, 1, 10**6)])
 def test_batch_knn_u8_exact_engine(S, innr, n, dim, nq, k):
     alpha, offset = 2.0, -1.0
     codes = _codes(n, dim, 3)

@@ -1053,6 +1053,10 @@ static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, siz
                                  size_t kout, uint64_t* d_out_idx, float* d_out_score) {
     innr_ctx* c = b->ctx;
     const size_t ldq = round_up(D ? D : 1, 4), N = b->N;
+    if (N > 0x7fffffffull) {  // rocPRIM's item count is an int
+        set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 vectors per batch (N=%zu)", kout, N);
+        return INNR_E_UNSUPPORTED;
+    }
     size_t tmp_bytes = 0;
     INNR_HIP_CHECK(full_sort_scratch_bytes(N, &tmp_bytes));
     INNR_TRY(c->q_one.ensure(ldq * sizeof(float)));
@@ -1937,6 +1941,10 @@ static innr_status maxsim_topk_exact(innr_docs* d, int cosine, const float* qtok
     INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, d->dim));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     if (kout > INNR_MAX_K) {  // more results than a candidate list holds: sort all document scores (cf. knn_full_sort)
+        if (d->ndocs > 0x7fffffffull) {
+            set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 documents", kout);
+            return INNR_E_UNSUPPORTED;
+        }
         size_t tmp_bytes = 0;
         INNR_HIP_CHECK(full_sort_scratch_bytes(d->ndocs, &tmp_bytes));
         INNR_TRY(c->sort_keys.ensure(2 * d->ndocs * sizeof(uint64_t)));

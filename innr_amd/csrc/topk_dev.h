@@ -62,10 +62,12 @@ __device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_
     (void)__hip_atomic_fetch_max(slots + (idx & (KP - 1)), pref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // KP = 2^n
 }
 // Slots per query = kSlotMul * KP. With exactly KP slots the bound is the MINIMUM of KP bucket maxima, which sits near
-// global rank KP*ln(KP) (coupon collector: every bucket must have been hit); with 4*KP slots the bound is the KP-th
-// LARGEST bucket maximum -- still a certificate of KP distinct vectors -- and sits near rank 1.15*KP.
+// global rank KP*ln(KP) (coupon collector: every bucket must have been hit); with more slots the bound is the KP-th
+// LARGEST bucket maximum -- still a certificate of KP distinct vectors -- and sits much closer to rank KP. 2*KP slots:
+// measured at C2 with tools/gemm_probe.hip: KP = 32: 109.3 / 108.8 / 108.9 ms for 1 / 2 / 4 * KP slots, KP = 128:
+// 114.5 / 112.7 / 114.3 (more slots = tighter bound but more loads and compares per re-derivation).
 #ifndef INNR_SLOT_MUL
-#define INNR_SLOT_MUL 4
+#define INNR_SLOT_MUL 2
 #endif
 constexpr uint32_t kSlotMul = INNR_SLOT_MUL;
 

@@ -5,20 +5,22 @@
 // (:756-758) / batch_cosine_into epilogue (:713-727)  for a whole batch of queries.
 //
 // Roofline: MFMA-bound. 2*Q*N*D flop; v_mfma_f32_32x32x2_f32 = 64 flop/clk/SIMD = 157.3 TFLOP/s chip peak.
-// The corpus is streamed once per query tile (<= Q/256 times): far below the HBM roof.
+// The corpus is streamed once per query tile (Q/512 or Q/256 times): far below the HBM roof.
 //
 // Mapping (CDNA4, wave64):
 //   S^T[corpus i][query j] = sum_d V[d][i] * Qt[d][j]     A = corpus (MFMA rows), B = queries (MFMA cols)
 //   Both operands are K-major in memory: the PDX layout V[d*ldN + i] IS the A operand's layout (lane l needs
 //   A[i = l&31][k = l>>5], i.e. 32 consecutive floats of one dimension row), and the queries are transposed
 //   once per call to Qt[d*Qpad + j]. No in-kernel transpose, every global and LDS access is contiguous.
-//   Block = 256 threads = 4 waves, tile 128 corpus x 256 queries x BK 16; wave w owns queries [64w, 64w+64)
-//   x all 128 corpus rows = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs).
-//   Corpus tile (shared by the 4 waves): LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring of 8 KiB, two
+//   Block = 4 or 8 waves (template parameter WAVES), tile 128 corpus x 64*WAVES queries x BK 16; wave w owns queries
+//   [64w, 64w+64) x all 128 corpus rows = 4 x 2 MFMA tiles of 32x32 (128 accumulator VGPRs).
+//   Corpus tile (shared by the block's waves): LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring of 8 KiB, two
 //   K-steps ahead; one ds_read_b128 per lane yields the A fragments of FOUR row tiles at once (tile rt holds
 //   corpus rows 4r+rt), conflict-free. Query operands (private to a wave): plain 8-byte loads from the L2-resident
-//   Qt straight into registers, one K-step ahead -- they never touch LDS. One barrier per K-step; 26 KiB LDS and
-//   <= 256 VGPRs keep two blocks resident per CU, so one block's epilogue (VALU) overlaps the other's MFMAs.
+//   Qt straight into registers, one K-step ahead -- they never touch LDS. One barrier per K-step; 26-28 KiB LDS and
+//   <= 256 VGPRs keep 8 waves resident per CU: two 4-wave blocks (one block's epilogue overlaps the other's MFMAs) or
+//   one 8-wave block (corpus streamed half as often).
+//   All global addresses are a wave-uniform 64-bit base (advanced on the scalar unit) + a constant 32-bit lane offset.
 //   The wave that owns a query owns its candidate list: no cross-wave synchronisation in the epilogue.
 //   Block -> (slice, query tile): one query tile per XCD group (its 768 KiB stay in that L2); placement only
 //   affects speed.
@@ -32,8 +34,8 @@ namespace innr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // waves per block (template parameter WAVES): 4 = 256-query tile, two blocks per CU; 8 = 512-query tile, one block per
-// CU. Same speed at C2 (113.9 vs 114.1 ms); the 8-wave block streams the corpus once per 512 queries instead of once
-// per 256, halving the L2-miss traffic, so it is used whenever there are more than 256 queries.
+// CU, the corpus streamed once per 512 queries instead of once per 256 (half the L2-miss traffic). plan_gemm (api.hip)
+// picks 8 for the dot kind with more than 256 queries (same speed) and 4 for cosine / L2 / u8 (0.6-1 ms faster at C2).
 constexpr int kBC = 128;   // corpus rows per block tile
 constexpr int kBQmax = 512;  // queries per block tile = 64 per wave
 constexpr int kBK = 16;    // K-step
@@ -86,10 +88,12 @@ __device__ __forceinline__ uint32_t lds_addr_uniform(const void* p) {
 //      tools/gemm_probe.hip attributed 12 % of the kernel time to exactly that traffic.)
 //
 // vmcnt counts every VMEM op of the wave in issue order (DMA, query loads, epilogue loads/stores alike). Per step a
-// wave issues, in this order: corpus DMA of step s+2 (2 ops; u8: 1 or 0), then 8 query loads for step s+1. The
-// compiler inserts the waits for the query loads (it does not see the inline-asm DMA, so its counts are only ever
-// stricter than needed, and never so strict as to wait for the youngest DMA); the end-of-step wait below leaves
-// exactly those youngest ops in flight: the corpus pieces of step s+1 (issued during s-1) are then in LDS.
+// wave issues, in this order and in EVERY step (past the end of its slice into stages / registers nobody reads): the
+// corpus DMA of step s+2 (2 ops; 1 for u8 and for 8-wave blocks), then 4 x 2 query loads for step s+1, each pair
+// right after the MFMA group that consumed its registers. All waits are hand-counted inline asm (use_after<N> before
+// a group's operands, wait_but_youngest<N> at the end of the step): the constant sequence is what makes the counts
+// constants. tools/check_gemm_asm.py verifies in the ISA that the operand registers are only touched by those loads
+// and the MFMAs.
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #ifdef INNR_GEMM_PROBE_NOWAIT  // tools/gemm_probe.hip: issue the DMA but never wait for it
 template <int N> __device__ __forceinline__ void wait_but_youngest() {}

@@ -323,3 +323,19 @@ def test_knn_large_k_ties_keep_index_order(B, innr):
     data = oracle.from_rows(rows)
     _check_knn(B, innr, "dot", rows, data, _queries(2, 24, 7, uniform=True), 1000, innr.KNN_AUTO)
     _check_knn(B, innr, "cos", rows, data, _queries(2, 24, 7, uniform=True), 600, innr.KNN_AUTO)
+
+
+def test_knn_large_k_nan_inf_zero_ordering(B, innr):
+    # the complete ranking (k = N > INNR_MAX_K) with +NaN, +-inf and +-0.0 scores in it: total_cmp order end to end
+    rows = oracle.generate_corpus(600, 8, 1)
+    rows[17, 3] = np.nan
+    rows[300, 0] = np.inf
+    rows[301, 0] = -np.inf
+    rows[5] = 0.0
+    rows[6] = -0.0
+    data = oracle.from_rows(rows)
+    q = np.float32([1, 1, 1, 1, 1, 1, 1, 1])
+    for metric in ("dot", "l2"):
+        _check_knn(B, innr, metric, rows, data, q.reshape(1, -1), 600, innr.KNN_AUTO)
+    r = B.batch_knn_dot(q, B.VerticalBatch.from_rows(rows), 600)
+    assert r.indices[:2] == [17, 300] and r.indices[-1] == 301 and len(set(r.indices)) == 600

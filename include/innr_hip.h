@@ -49,6 +49,11 @@ typedef int innr_status;
 #define INNR_KNN_AUTO 0  /* MFMA GEMM for query batches, exact scan for small batches */
 #define INNR_KNN_EXACT 1 /* bit-exact VALU scan in the reference's arithmetic order (HBM-bound) */
 #define INNR_KNN_MFMA 2  /* f32 MFMA GEMM + fused top-k filter + exact re-score (MFMA-bound) */
+#define INNR_KNN_MFMA_BF16 3 /* the same with the FILTER on the bf16 matrix pipe (16x the f32 MFMA rate) over a K-packed bf16
+                              * copy of the corpus built on first use (+ N*D*2 bytes of HBM). Results are unchanged -- the
+                              * candidates are re-scored in the reference's f32 order and the answer is proven against the
+                              * bf16 error bound, unproven queries are redone exactly. Dot metric with k <= 48; every other
+                              * call is served by INNR_KNN_MFMA (innr_knn_stats.engine tells). Not chosen by INNR_KNN_AUTO. */
 
 #define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). innr_batch_knn[_dev] and
                         * innr_batch_knn_u8[_dev] accept any k: beyond INNR_MAX_K they compute all N scores and sort them on
@@ -61,7 +66,7 @@ typedef struct innr_batch innr_batch; /* device-resident VerticalBatch (PDX, dim
 
 /* what a kNN call did (optional out-parameter; all fields written) */
 typedef struct innr_knn_stats {
-    int engine;                 /* INNR_KNN_EXACT or INNR_KNN_MFMA actually used */
+    int engine;                 /* INNR_KNN_EXACT, INNR_KNN_MFMA or INNR_KNN_MFMA_BF16 actually used */
     uint32_t queries_fallback;  /* MFMA engine: queries whose margin proof failed and were redone exactly */
     uint32_t candidates_kept;   /* k' = candidates per query kept before the exact re-score */
     float gemm_ms;              /* device time of the dominant kernel (HIP events on the ctx stream) */

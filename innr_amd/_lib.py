@@ -32,6 +32,7 @@ METRIC_COSINE = 2
 KNN_AUTO = 0
 KNN_EXACT = 1
 KNN_MFMA = 2
+KNN_MFMA_BF16 = 3  # bf16 filter + exact f32 re-score (dot, k <= 48); same results
 
 MAX_K = 240
 

@@ -12,6 +12,7 @@
 #include "kernels_scan.h"
 #include "kernels_topk.h"
 #include "kernels_gemm.h"
+#include "kernels_gemm_bf16.h"
 #include "kernels_ext.h"
 #include "kernels_u8.h"
 #include "kernels_maxsim.h"
@@ -90,6 +91,7 @@ struct innr_ctx {
     DevBuf seed_idx;   // threshold seeding: exact top-KP of a corpus prefix (indices unused, scores -> bounds)
     DevBuf seed_score;
     DevBuf misc;
+    DevBuf q_bf16;     // bf16 filter engine: K-packed bf16 queries
     DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
     DevBuf sort_keys;  // [2][N] composites: unsorted, sorted
     DevBuf sort_tmp;   // radix sort scratch
@@ -150,6 +152,9 @@ struct innr_batch {
     // innr_batch_prefix_view: V / C8 belong to another batch (never freed here). Rows D..Dpad of a view can hold the
     // parent's next dimensions instead of zero padding; the GEMM engine (which multiplies all Dpad rows) is then off.
     bool is_view = false, gemm_ok = true;
+    // bf16 filter engine (kernels_gemm_bf16.h): K-packed bf16 copy of the corpus, built on first use, always owned
+    char* Ab = nullptr;
+    uint32_t ab_nk = 0;
 };
 
 namespace innr {
@@ -492,13 +497,69 @@ static innr_status ensure_sqnorms(innr_batch* b) {
     return INNR_OK;
 }
 
+// ---- bf16 filter engine (kernels_gemm_bf16.h) ------------------------------------------------------------------
+static uint32_t bf16_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 64) / 32); }  // K-steps of 32, even
+
+static innr_status ensure_bf16_corpus(innr_batch* b) {
+    if (b->Ab) return INNR_OK;
+    const uint32_t nk = bf16_nk(b);
+    const size_t units = (b->ldN / 128) * (size_t)nk * 512;  // 16-byte units
+    hipError_t e = hipMalloc((void**)&b->Ab, units * 16);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for the bf16 corpus copy failed: %s", units * 16, hipGetErrorString(e));
+        b->Ab = nullptr;
+        return INNR_E_OOM;
+    }
+    pack_corpus_bf16_kernel<<<(unsigned)((units + 255) / 256), 256, 0, b->ctx->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk,
+                                                                                     units, reinterpret_cast<uint4*>(b->Ab));
+    INNR_HIP_CHECK(hipGetLastError());
+    b->ab_nk = nk;
+    return INNR_OK;
+}
+
+static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, const uint32_t* seed) {
+    innr_ctx* c = b->ctx;
+    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
+    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
+    INNR_TRY(c->gthr.ensure(gbytes));
+    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
+    uint32_t* gslots = c->gthr.as<uint32_t>();
+    if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+#define INNR_BF16_LAUNCH(RR)                                                                                              \
+    gemm_bf16_filter_kernel<RR, 0><<<p.nblocks, 64 * kBfWaves, 0, c->stream>>>(                                             \
+        b->Ab, c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps,      \
+        c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, nullptr, 0)
+    switch (p.cap) {
+        case 384: INNR_BF16_LAUNCH(6); break;
+        case 512: INNR_BF16_LAUNCH(8); break;
+        case 768: INNR_BF16_LAUNCH(12); break;
+        default: INNR_BF16_LAUNCH(20); break;
+    }
+#undef INNR_BF16_LAUNCH
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
 static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* /*dQn*/,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
-                            float* gemm_ms) {
+                            float* gemm_ms, bool bf16 = false) {
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
-    const GemmPlan p = plan_gemm(b, Q, kout, 0, !cos && !l2);
     INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
+    // bf16 filter: dot kind, candidate lists of 4k + 64 (its bound E is ~2^-7 |q||v|, so the k-th exact score must clear
+    // the KP-th approximate one by a visible margin), a corpus whose scores are far from the denormal range
+    const bool use_bf16 = bf16 && !cos && !l2 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
+                          (b->max_norm - b->max_norm == 0.0f);
+    GemmPlan p = plan_gemm(b, Q, kout, use_bf16 ? 8 : 0, !cos && !l2);
+    if (use_bf16) {
+        p.KP = pick_kp(4 * kout + 64, 0);
+        p.cap = (uint32_t)cand_cap((int)p.KP);
+        INNR_TRY(ensure_bf16_corpus(b));
+        INNR_TRY(c->q_bf16.ensure((size_t)b->ab_nk * 4 * p.Qpad * 16));
+        pack_queries_bf16_kernel<<<(unsigned)(((size_t)b->ab_nk * 4 * p.Qpad + 255) / 256), 256, 0, c->stream>>>(
+            dQ, (uint32_t)Q, (uint32_t)b->D, b->ab_nk, (uint32_t)p.Qpad, reinterpret_cast<uint4*>(c->q_bf16.p));
+        INNR_HIP_CHECK(hipGetLastError());
+    }
     if (cos) INNR_TRY(ensure_invnorms(b));
     if (l2) INNR_TRY(ensure_sqnorms(b));
     INNR_TRY(prep_queries(b, p, dQ, Q, cos));
@@ -525,7 +586,11 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     // reference's own direct-difference sum is within (D+2) u of the true distance: every term is <= C = (|q|+max|v|)^2,
     // so |(C - approx) - exact| <= (6D+40) u C with room to spare.
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
-    const float err_scale = l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm);
+    // bf16 filter: both operands rounded to 8 significant bits (|delta| <= 2^-8 each): |q'v' - qv| <= (2^-7 + 2^-16) |qv|,
+    // plus the f32 accumulation of the rounded products
+    const float bf16_scale = 1.05f * (0.0078125f * 1.004f + (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f * 1.02f) * b->max_norm;
+    const float err_scale = use_bf16 ? bf16_scale
+                                     : (l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm));
 
     // threshold seeding from the exact top-KP of a corpus prefix (seed_thresholds_kernel)
     const uint32_t* seed = nullptr;
@@ -551,6 +616,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
     if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
     else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
+    else if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, seed));
     else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
@@ -575,8 +641,13 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     INNR_HIP_CHECK(hipGetLastError());
 
     std::vector<uint32_t> fb(Q);
+    std::vector<float> qn_host(use_bf16 ? Q : 0);
     INNR_HIP_CHECK(copy_out(c, fb.data(), fallback, Q * sizeof(uint32_t)));
+    if (use_bf16) INNR_HIP_CHECK(copy_out(c, qn_host.data(), c->q_norm.p, Q * sizeof(float)));
     INNR_HIP_CHECK(ctx_sync(c));
+    // bf16 products / sums below the normal range may be flushed to zero: the bound E must dwarf that, else redo exactly
+    for (size_t q = 0; q < qn_host.size(); ++q)
+        if (!(qn_host[q] * b->max_norm >= 1e-25f)) fb[q] = 1;
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
     uint32_t nf = 0;
@@ -587,6 +658,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     }
     *nfallback = nf;
     *kept = p.KP;
+    if (bf16 && !use_bf16) *gemm_ms = -*gemm_ms;  // told apart by the caller: the f32 engine served this call
     return INNR_OK;
 }
 
@@ -657,7 +729,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp};
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)
@@ -786,6 +858,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->invn) (void)hipFree(b->invn);
     if (b->sqn) (void)hipFree(b->sqn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
+    if (b->Ab) (void)hipFree(b->Ab);
     delete b;
 }
 
@@ -1127,7 +1200,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
-    if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
+    if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
@@ -1142,8 +1215,13 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     }
     uint32_t nfallback = 0, kept = 0;
     float gemm_ms = 0.0f;
-    if (engine == INNR_KNN_MFMA) {
-        INNR_TRY(knn_mfma(b, metric, d_queries, Q, kout, dQn, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
+    if (engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) {
+        INNR_TRY(knn_mfma(b, metric, d_queries, Q, kout, dQn, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms,
+                          engine == INNR_KNN_MFMA_BF16));
+        if (gemm_ms < 0.0f) {  // not a dot-kind call / k too large / degenerate norms: the f32 engine served it
+            gemm_ms = -gemm_ms;
+            engine = INNR_KNN_MFMA;
+        }
     } else if (kout > INNR_MAX_K) {
         INNR_TRY(knn_full_sort(b, metric, d_queries, D, dQn, Q, kout, d_out_idx, d_out_score));
         kept = (uint32_t)b->N;

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
+    constexpr int kEpiTgWait = 10;  // gemm_epilogue.inc: at most 10 VMEM ops of this wave are in flight at a tile end
     const float* V = static_cast<const float*>(Vraw);
     const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
     constexpr int kGemmWaves = WAVES, kBQ = 64 * WAVES;
@@ -360,187 +361,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
 #else
         if (ks + 1 == nk) {
 #endif
-            // ---------------- epilogue for corpus tile `tile` ----------------
-            const size_t tb = (size_t)tile * kBC;
-            const int half = lane >> 5, C = lane & 31;
-            if (MODE == 1) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const size_t q = q0 + 64 * w + 2 * C + ct;
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g) {
-                            const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
-                            float v = acc[rt][ct][g];
-                            if (COS) v = v * invn[i] * invq[q];
-                            if (U8) v = v * scale + invq[q];
-                            dump[q * ld_dump + i] = v;
-                        }
-                }
-            } else {
-                // Threshold of each of this lane's two queries: the better of the list's own (KP-th best it holds)
-                // and the chip-wide bound gthr[q] (topk_dev.h, global threshold slots).
-                uint32_t thr[2];
-                use_after<10>(tg_next[0], tg_next[1]);  // requested a whole tile ago (or before the first K-step)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const uint32_t tl = __hip_atomic_load(&s.thr[64 * w + 2 * C + ct], __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    // chip-wide bound as read at the end of the previous tile's epilogue: one tile stale (a stale
-                    // bound is only weaker), but its L2 round trip is no longer on this wave's critical path
-                    thr[ct] = tl > tg_next[ct] ? tl : tg_next[ct];
-                }
-                // Fast reject. For a threshold that is a non-negative float (the normal case once a list has KP
-                // entries), "some value >= thr in total order" == "max over RAW BIT PATTERNS compared as signed
-                // ints >= raw(thr)": non-negative floats (and +NaN, the greatest) order like their bits and every
-                // negative float is a negative int. One v_max per value, no key conversion, NaN-safe.
-                int32_t best[2] = {INT32_MIN, INT32_MIN};
-                const float iq[2] = {iq_lane[0], iq_lane[1]};
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {  // 16 consecutive corpus rows: tb + 4*(8*gq + 4*half) + [0,16)
-                    const float4* p = reinterpret_cast<const float4*>(invn + tb + 4 * (8 * gq + 4 * half));
-#pragma unroll
-                    for (int g3 = 0; g3 < 4; ++g3) {
-                        float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // 1/||v|| of corpus rows 4*(g3 + ...) + rt
-                        if (COS || L2K) {
-                            const float4 t = p[g3];
-                            sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
-                        }
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                            for (int rt = 0; rt < 4; ++rt) {
-                                float v = acc[rt][ct][4 * gq + g3];
-                                if (COS) {
-                                    v = v * sc[rt] * iq[ct];
-                                    acc[rt][ct][4 * gq + g3] = v;
-                                }
-                                if (U8) {
-                                    v = v * scale + iq[ct];
-                                    acc[rt][ct][4 * gq + g3] = v;
-                                }
-                                if (L2K) {
-                                    v = (2.0f * v + iq[ct]) - sc[rt];
-                                    acc[rt][ct][4 * gq + g3] = v;
-                                }
-                                const int32_t raw = (int32_t)__float_as_uint(v);
-                                best[ct] = best[ct] > raw ? best[ct] : raw;
-                            }
-                    }
-                    // keep the scheduler from hoisting all 16 norm loads (64 registers) above the first use: with the
-                    // 128 accumulators live that is what pushed the cosine / L2 instantiations into scratch
-                    if (COS || L2K) __builtin_amdgcn_sched_barrier(0);
-                }
-                bool hit[2];
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const bool nonneg_thr = (thr[ct] & 0x80000000u) != 0;  // ord of a non-negative float
-                    hit[ct] = !nonneg_thr || best[ct] >= (int32_t)(thr[ct] & 0x7fffffffu);
-                }
-#ifdef INNR_GEMM_PROBE_SKIPHIT  // tools/gemm_probe.hip: thresholds + fast reject only, never the append path
-                if (__any(hit[0] || hit[1]) && dump != nullptr) {
-#else
-                if (__any(hit[0] || hit[1])) {
-#endif
-#ifdef INNR_GEMM_PROBE_COUNT  // tools/gemm_probe.hip: how often the append path runs and how much it appends
-                    if (lane == 0) atomicAdd(errflag + 8, 1u);
-                    atomicAdd(errflag + 9, (uint32_t)hit[0] + (uint32_t)hit[1]);
-                    const long long t_hit0 = __builtin_readcyclecounter();
-#endif
-                    unsigned long long admitted_by[2] = {0ull, 0ull};  // lanes whose query (2*lane + ct) admitted something
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const int ql = 64 * w + 2 * C + ct;
-                        uint64_t* lq = my_lists + (size_t)ql * cap;
-                        bool admitted = false;
-                        if (hit[ct]) {
-                            // One compare + branch per value on the way past the 64 sites: "not (v < t)" with t the float
-                            // whose order key is thr is a superset of "key(v) >= thr" (it also passes NaNs and -0 vs +0
-                            // ties; thr = 0, "no bound", maps to a NaN and passes everything). The exact key test follows
-                            // inside. The key conversion per site made this scan ~8K cycles per entry -- and a wave in
-                            // here holds up its whole block at the next K-step barrier. (Walking the values with a
-                            // runtime loop over a per-wave LDS stage instead -- one copy of the append code, kernel 12.5
-                            // instead of 33 KB -- was tried: 18K cycles per entry instead of 7.5K, +1.2 ms.)
-                            const float thr_f = ord_f32(thr[ct]);
-#pragma unroll
-                            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                                for (int g = 0; g < 16; ++g) {
-                                    if (acc[rt][ct][g] < thr_f) continue;
-                                    const uint32_t o = f32_ord(acc[rt][ct][g]);
-                                    const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
-                                    if (o >= thr[ct] && i < N) {
-                                        admitted = true;
-#ifdef INNR_GEMM_PROBE_COUNT
-                                        atomicAdd(errflag + 10, 1u);
-#endif
-                                        cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
-                                        gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
-                                    }
-                                }
-                        }
-                        admitted_by[ct] = __ballot(admitted);
-                    }
-#ifdef INNR_GEMM_PROBE_COUNT
-                    const long long t_hit1 = __builtin_readcyclecounter();
-#endif
-                    // re-derive the chip-wide bound of every query that admitted something: the whole wave reads the KP
-                    // slots of one query at a time (two lanes hold the same query pair: only the lower half reports)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        unsigned long long m = admitted_by[ct];
-                        m = (m | (m >> 32)) & 0xffffffffull;  // lanes l and l+32 own the same two queries
-                        while (m) {
-                            const int L = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const size_t qg = q0 + 64 * wu + 2 * L + ct;  // wave-uniform
-                            if (kSlotMul == 1) gthr_publish_scalar(gslots + qg * (size_t)KP, gthr + qg, KP, lane);
-                            else gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);  // KP == 16 R - 64 (cand_cap)
-                        }
-                    }
-#ifdef INNR_GEMM_PROBE_COUNT
-                    const long long t_hit2 = __builtin_readcyclecounter();
-                    if (lane == 0) {
-                        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 14), (unsigned long long)(t_hit1 - t_hit0));
-                        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 16), (unsigned long long)(t_hit2 - t_hit1));
-                    }
-#endif
-                    __builtin_amdgcn_wave_barrier();
-                    // compact the lists of this wave's queries that are running out of room
-                    const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    unsigned long long need = __ballot(c > cap - kGemmBurst);
-                    while (need) {
-                        const int j = __builtin_ctzll(need);
-                        need &= need - 1;
-                        const int ql = 64 * w + j;
-                        const uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                        uint32_t t;
-                        const uint32_t keep = wave_compact<R>(my_lists + (size_t)ql * cap, cj, KP, &t);
-                        if (lane == 0) {
-                            s.cnt[ql] = keep;
-                            s.thr[ql] = t;
-                            // a list's own KP-th best is a valid chip-wide bound too
-                            if (t > __hip_atomic_load(&gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                __hip_atomic_fetch_max(&gthr[q0 + ql], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#ifdef INNR_GEMM_PROBE_COUNT
-                    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 12), (unsigned long long)(__builtin_readcyclecounter() - t_hit0));
-#endif
-                }
-            }
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0.0f;
-            if (MODE == 0) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + ct, 8u * (uint32_t)(lane & 31));
-            }
+#include "gemm_epilogue.inc"
             ks = 0;
             ++tile;
         } else {

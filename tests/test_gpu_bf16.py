@@ -1,0 +1,67 @@
+"""GPU parity tests of the bf16 FILTER engine (INNR_KNN_MFMA_BF16, kernels_gemm_bf16.h): approximate scores on the bf16
+matrix pipe, candidates re-scored in the reference's f32 order, answers proven against the bf16 error bound. The bar is
+the same as for every engine: scores bit-identical to the oracle's, index lists identical."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from test_gpu_exact import B, _check_knn, _corpus, _queries, bits_equal, innr, same_knn  # noqa: F401  (fixtures)
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(10_000, 128, 100, 10), (20_000, 100, 513, 10), (70_000, 64, 600, 10), (3000, 20, 300, 48),
+                                        (257, 33, 5, 16), (1000, 64, 9, 33), (5, 3, 2, 10), (200_000, 32, 40, 1)])
+def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k):
+    rows, data = _corpus(n, dim, 77, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    qs = _queries(nq, dim, 4242, uniform=True)
+    st = innr.KnnStats()
+    idx, sc = B.batch_knn_dot_multi(qs, vb, k, engine=innr.KNN_MFMA_BF16, stats=st)
+    assert st.engine == innr.KNN_MFMA_BF16
+    for j, q in enumerate(qs):
+        oi, os_ = oracle.batch_knn_dot(q, data, k)
+        assert same_knn("dot", idx[j], sc[j], oi, os_), (j, idx[j], oi, sc[j], os_)
+    if n >= 10_000:  # well-separated uniform data: (almost) every answer is proven, few queries redone exactly
+        assert st.queries_fallback <= max(2, nq // 20), st.queries_fallback
+
+
+def test_bf16_filter_near_ties_are_redone_exactly(B, innr):
+    # the reference example's LCG data: a one-parameter family with seas of near-ties; proofs fail, results must not
+    rows, data = _corpus(10_000, 128, 0)
+    _check_knn(B, innr, "dot", rows, data, _queries(40, 128), 10, innr.KNN_MFMA_BF16)
+
+
+def test_bf16_engine_serves_other_kinds_on_the_f32_engine(B, innr):
+    rows, data = _corpus(70_000, 64, 5, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    qs = _queries(20, 64, 9, uniform=True)
+    for metric, fn in (("cos", B.batch_knn_cosine_multi), ("l2", B.batch_knn_multi)):
+        st = innr.KnnStats()
+        fn(qs, vb, 10, engine=innr.KNN_MFMA_BF16, stats=st)
+        assert st.engine == innr.KNN_MFMA
+        _check_knn(B, innr, metric, vb, data, qs, 10, innr.KNN_MFMA_BF16)
+    st = innr.KnnStats()
+    B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_BF16, stats=st)  # k > 48: candidate lists would not fit
+    assert st.engine == innr.KNN_MFMA
+    _check_knn(B, innr, "dot", vb, data, qs, 100, innr.KNN_MFMA_BF16)
+
+
+def test_bf16_filter_tiny_and_special_values(B, innr):
+    # scores near the denormal range (bf16 products may flush): the engine must hand those to the exact path
+    rows, data = _corpus(70_000, 64, 3, uniform=True)
+    tiny = (rows * np.float32(1e-20)).astype(np.float32)
+    qs = _queries(6, 64, 1, uniform=True)
+    _check_knn(B, innr, "dot", tiny, oracle.from_rows(tiny), (qs * np.float32(1e-18)).astype(np.float32), 10, innr.KNN_MFMA_BF16)
+    rows[17, 3] = np.inf  # a non-finite norm: nothing can be proven
+    _check_knn(B, innr, "dot", rows, oracle.from_rows(rows), qs, 5, innr.KNN_MFMA_BF16)
+
+
+def test_bf16_filter_on_a_prefix_view(B, innr):
+    rows, data = _corpus(70_000, 128, 11, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    v = vb.prefix(64)
+    _check_knn(B, innr, "dot", v, np.ascontiguousarray(data[:64]), np.ascontiguousarray(_queries(30, 128, 99, uniform=True)[:, :64]), 10,
+               innr.KNN_MFMA_BF16)

@@ -617,6 +617,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
     else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
     else if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, seed));
+    // (A first pass of the same kernel over 1/16 of the corpus, only to harvest tighter bounds for the full pass, was
+    //  tried: 17.6 ms for both against 16.4 for the single pass.)
     else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 

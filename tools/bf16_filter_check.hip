@@ -83,7 +83,7 @@ static int speed_test(size_t N, int KPsel) {
     pack_queries_bf16_kernel<<<(unsigned)(((size_t)nk * 4 * Qpad + 255) / 256), 256>>>(dQ, (uint32_t)Q, (uint32_t)D, nk, (uint32_t)Qpad, (uint4*)Bb);
     float best = 1e9;
     for (int it = 0; it < 4; ++it) {
-        CK(hipMemset(gs, 0, gwords * 4));
+        if (!(getenv("PROBE_KEEP") && it > 0)) CK(hipMemset(gs, 0, gwords * 4));  // PROBE_KEEP=1: later launches start from the final bounds
         CK(hipEventRecord(a));
         if (KP == 32) gemm_bf16_filter_kernel<6, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
         else gemm_bf16_filter_kernel<12, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);

@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
 s = open(path).read()
-names = [n for n in re.findall(r"^(_ZN4innr18gemm_filter_kernel\S+):", s, flags=re.M) if not n.endswith(".kd")]
+names = [n for n in re.findall(r"^(_ZN4innr(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel)\S+):", s, flags=re.M) if not n.endswith(".kd")]
 if not names:
     sys.exit("no gemm_filter_kernel in " + path)
 bad_total = 0
@@ -29,18 +29,25 @@ for name in names:
         if ";;#ASMSTART" in line:
             j = k + 1
             while j < len(body) and ";;#ASMEND" not in body[j]:
-                m = re.match(r"\s*global_load_dwordx2 v\[(\d+):(\d+)\]", body[j])
+                m = re.match(r"\s*global_load_dwordx[24] v\[(\d+):(\d+)\]", body[j])
                 if m:
                     pairs.add((int(m.group(1)), int(m.group(2))))
                 j += 1
     flat = {r for a, b in pairs for r in range(a, b + 1)}
     bad = []
+    # the operand registers carry in-flight loads from the first asm load to the last MFMA; outside that window they
+    # are ordinary registers (zero-initialisation before, the final list compaction after)
+    loads = [k for k, l in enumerate(body) if re.match(r"\s*global_load_dwordx[24] v\[", l)]
+    mfmas = [k for k, l in enumerate(body) if l.strip().startswith("v_mfma")]
+    lo, hi = (loads[0] if loads else 0), (mfmas[-1] if mfmas else len(body))
     for k, line in enumerate(body):
+        if k < lo or k > hi:
+            continue
         t = line.split(";")[0].strip()
         if not t or t.startswith("."):
             continue
         op = t.split()[0]
-        if op.startswith(("v_mfma", "global_load_dwordx2", "s_")):
+        if op.startswith(("v_mfma", "global_load_dwordx2", "global_load_dwordx4", "s_")):
             continue
         used = set()
         for mm in re.finditer(r"v\[(\d+):(\d+)\]", t):
@@ -61,10 +68,11 @@ for name in names:
         if src_regs & flat:
             # reading a pair as the ADDRESS of its own reload (v_lshl_add_u64 vX, vX ... ; global_load vX, vX) is fine
             nxt = " ".join(body[k + 1:k + 4])
-            if op.startswith("v_lshl_add_u64") and re.search(r"global_load_dwordx2 " + re.escape(dst), nxt):
+            if op.startswith("v_lshl_add_u64") and re.search(r"global_load_dwordx[24] " + re.escape(dst), nxt):
                 continue
             bad.append(t)
     short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3,\4>", name)
+    short = re.sub(r".*gemm_bf16_filter_kernelILi(\d+)ELi(\d+)E.*", r"bf16<\1,\2>", short)
     status = "ok" if (len(pairs) == 8 and not bad) else "FAIL"
     print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads  {status}")
     for b in bad[:5]:

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(64 * kBfWaves, 1) void gemm_bf16_filter_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
-            if (ks + 1 == nk) {
+            // nk is a multiple of kBfLead, so a tile always ends on the last ring position: ONE copy of the epilogue in
+            // the unrolled loop (two copies made the kernel 81 KB, more than the 64 KB instruction cache)
+            if (r == kBfLead - 1 && ks + 1 == nk) {
 #include "gemm_epilogue.inc"
                 ks = 0;
                 ++tile;

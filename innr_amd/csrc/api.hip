@@ -1612,6 +1612,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
+    if (engine == INNR_KNN_MFMA_BF16) engine = INNR_KNN_MFMA;  // codes are widened on the f32 pipe: no bf16 variant
     if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;
     uint32_t nfallback = 0, kept = kout > INNR_MAX_K ? (uint32_t)b->N : pick_kp(kout, 0);

@@ -29,6 +29,9 @@ pub mod ffi {
     pub const INNR_METRIC_L2SQ: c_int = 1;
     pub const INNR_METRIC_COSINE: c_int = 2;
     pub const INNR_KNN_AUTO: c_int = 0;
+    pub const INNR_KNN_EXACT: c_int = 1;
+    pub const INNR_KNN_MFMA: c_int = 2;
+    pub const INNR_KNN_MFMA_BF16: c_int = 3; // bf16 filter + exact f32 re-score and proof: same results (dot, k <= 48)
     extern "C" {
         pub fn innr_ctx_create(device: c_int, out: *mut *mut InnrCtx) -> c_int;
         pub fn innr_ctx_destroy(ctx: *mut InnrCtx);
@@ -209,11 +212,15 @@ pub mod batch {
 
     /// Addition (the reference has no multi-query API): Q row-major queries at once; returns one result per query.
     pub fn batch_knn_multi(metric: i32, queries: &[f32], dimension: usize, batch: &VerticalBatch, k: usize) -> Vec<BatchKnnResult> {
+        batch_knn_multi_on(ffi::INNR_KNN_AUTO, metric, queries, dimension, batch, k)
+    }
+    /// The same on a named engine (ffi::INNR_KNN_EXACT / _MFMA / _MFMA_BF16): every engine returns the same results.
+    pub fn batch_knn_multi_on(engine: i32, metric: i32, queries: &[f32], dimension: usize, batch: &VerticalBatch, k: usize) -> Vec<BatchKnnResult> {
         assert_eq!(dimension, batch.dimension);
         let q = if dimension == 0 { 0 } else { queries.len() / dimension };
         let kk = k.min(batch.num_vectors);
         let (mut idx, mut sc, mut out_k) = (vec![0u64; q * kk.max(1)], vec![0f32; q * kk.max(1)], 0usize);
-        check(unsafe { ffi::innr_batch_knn(batch.handle(), metric, queries.as_ptr(), q, dimension, k, ffi::INNR_KNN_AUTO,
+        check(unsafe { ffi::innr_batch_knn(batch.handle(), metric, queries.as_ptr(), q, dimension, k, engine,
                                            idx.as_mut_ptr(), sc.as_mut_ptr(), &mut out_k, std::ptr::null_mut()) });
         (0..q).map(|j| BatchKnnResult {
             indices: idx[j * out_k..(j + 1) * out_k].iter().map(|&i| i as usize).collect(),

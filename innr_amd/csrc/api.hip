@@ -92,6 +92,7 @@ struct innr_ctx {
     DevBuf seed_score;
     DevBuf misc;
     DevBuf q_bf16;     // bf16 filter engine: K-packed bf16 queries
+    DevBuf redo_q, redo_idx, redo_sc, redo_map;  // bf16 filter engine: unproven queries, redone as ONE batch on the f32 engine
     DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
     DevBuf sort_keys;  // [2][N] composites: unsorted, sorted
     DevBuf sort_tmp;   // radix sort scratch
@@ -498,6 +499,20 @@ static innr_status ensure_sqnorms(innr_batch* b) {
 }
 
 // ---- bf16 filter engine (kernels_gemm_bf16.h) ------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ map, uint32_t n, uint32_t D,
+                                   float* __restrict__ dst) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)n * D) dst[t] = src[(size_t)map[t / D] * D + t % D];
+}
+__global__ void scatter_results_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ sc, const uint32_t* __restrict__ map,
+                                       uint32_t n, uint32_t k, uint64_t* __restrict__ out_idx, float* __restrict__ out_sc) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * k) return;
+    const size_t o = (size_t)map[t / k] * k + t % k;
+    out_idx[o] = idx[t];
+    out_sc[o] = sc[t];
+}
+
 static uint32_t bf16_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 64) / 32); }  // K-steps of 32, even
 
 static innr_status ensure_bf16_corpus(innr_batch* b) {
@@ -653,6 +668,39 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
     uint32_t nf = 0;
+    if (use_bf16) {
+        // The bf16 bound is ~2^15 times the f32 one: on data with small gaps at the cut many proofs fail. Those queries
+        // go through the f32 GEMM engine as ONE batch (its own proof, and the exact engine behind it) instead of one
+        // exact corpus scan each.
+        std::vector<uint32_t> redo;
+        for (size_t q = 0; q < Q; ++q)
+            if (fb[q]) redo.push_back((uint32_t)q);
+        if (redo.size() >= 4) {
+            const size_t nr = redo.size(), D = b->D;
+            INNR_TRY(c->redo_map.ensure(nr * sizeof(uint32_t)));
+            INNR_TRY(c->redo_q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
+            INNR_TRY(c->redo_idx.ensure(nr * kout * sizeof(uint64_t)));
+            INNR_TRY(c->redo_sc.ensure(nr * kout * sizeof(float)));
+            INNR_HIP_CHECK(hipMemcpyAsync(c->redo_map.p, redo.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            INNR_HIP_CHECK(hipStreamSynchronize(c->stream));  // redo is a pageable host vector
+            if (D) {
+                gather_rows_kernel<<<(unsigned)((nr * D + 255) / 256), 256, 0, c->stream>>>(dQ, c->redo_map.as<uint32_t>(), (uint32_t)nr,
+                                                                                        (uint32_t)D, c->redo_q.as<float>());
+                INNR_HIP_CHECK(hipGetLastError());
+            }
+            uint32_t nf2 = 0, kept2 = 0;
+            float ms2 = 0.0f;
+            INNR_TRY(knn_mfma(b, metric, c->redo_q.as<float>(), nr, kout, nullptr, c->redo_idx.as<uint64_t>(), c->redo_sc.as<float>(),
+                              &nf2, &kept2, &ms2, false));
+            scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(
+                c->redo_idx.as<uint64_t>(), c->redo_sc.as<float>(), c->redo_map.as<uint32_t>(), (uint32_t)nr, (uint32_t)kout, d_out_idx,
+                d_out_score);
+            INNR_HIP_CHECK(hipGetLastError());
+            *nfallback = (uint32_t)nr;
+            *kept = p.KP;
+            return INNR_OK;
+        }
+    }
     for (size_t q = 0; q < Q; ++q) {
         if (!fb[q]) continue;
         ++nf;  // margin proof failed (near-tie at the cut, or non-finite scores): redo this query exactly
@@ -731,7 +779,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16};
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->redo_q, &c->redo_idx, &c->redo_sc, &c->redo_map};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)

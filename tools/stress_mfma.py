@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import oracle
-from innr_amd import KNN_EXACT, KNN_MFMA, KnnStats
+from innr_amd import KNN_EXACT, KNN_MFMA, KNN_MFMA_BF16, KnnStats
 from innr_amd import batch as B
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+ENGINE = KNN_MFMA_BF16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else KNN_MFMA  # python tools/stress_mfma.py 30 bf16
 bad = 0
 shapes = [(10_000, 48, 70, 10), (40_000, 48, 70, 10), (3_333, 64, 300, 33), (200_000, 32, 40, 10), (1_000_000, 128, 256, 10),
           (500_000, 96, 1024, 10), (300_000, 64, 600, 16)]  # the last two run on 8-wave blocks (Q > 256, k <= 16)
@@ -19,7 +20,7 @@ for (n, dim, nq, k) in shapes:
     ei, es = B.batch_knn_dot_multi(qs, vb, k, engine=KNN_EXACT)
     for r in range(rounds):
         st = KnnStats()
-        mi, ms = B.batch_knn_dot_multi(qs, vb, k, engine=KNN_MFMA, stats=st)
+        mi, ms = B.batch_knn_dot_multi(qs, vb, k, engine=ENGINE, stats=st)
         if not (np.array_equal(mi, ei) and np.array_equal(ms.view(np.uint32), es.view(np.uint32))):
             bad += 1
             rows = np.where((mi != ei).any(axis=1))[0]

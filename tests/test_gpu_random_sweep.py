@@ -43,7 +43,8 @@ def test_random_knn_all_metrics_and_engines(seed):
     for metric in ("dot", "cos", "l2"):
         fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
         ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine, "l2": oracle.batch_knn}[metric]
-        for engine in (innr_amd.KNN_EXACT, innr_amd.KNN_MFMA):
+        # KNN_MFMA_BF16: bf16 filter for dot with k <= 48, served by the f32 engine otherwise -- same answers either way
+        for engine in (innr_amd.KNN_EXACT, innr_amd.KNN_MFMA, innr_amd.KNN_MFMA_BF16):
             idx, sc = fn(qs, vb, k, engine=engine)
             assert idx.shape == (nq, min(k, n))
             for j in range(nq):

@@ -149,14 +149,18 @@ def main() -> None:
 
     from innr_amd import KNN_MFMA, KNN_MFMA_BF16, METRIC_COSINE, METRIC_DOT, Context, KnnStats
     from innr_amd import batch as B
-    from innr_amd.dist import ShardedKnn
+    from innr_amd.dist import Comm, ShardedKnn
 
     metric = METRIC_DOT if args.metric == "dot" else METRIC_COSINE
     engine = KNN_MFMA_BF16 if args.engine == "bf16" else KNN_MFMA
     ctx = Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream for the kernels and the collective
     n_total = args.n_per_gpu * world
-    sk = ShardedKnn(n_total, rank=rank, world=world) if world > 1 else None
+    # N > 1: the exchange step runs inside the library (innr_sharded_knn_dev: local search + pack + ONE ncclAllGather of
+    # 8-byte entries + merge) on an RCCL communicator it owns; torch.distributed only carries the communicator id.
+    # (A one-GPU rehearsal with gloo has no RCCL: the same blocks then travel through torch.distributed.all_gather.)
+    comm = Comm.from_torch_group(ctx) if (world > 1 and dist.get_backend() == "nccl") else None
+    sk = ShardedKnn(n_total, rank=rank, world=world, comm=comm) if world > 1 else None
     row0 = rank * args.n_per_gpu
     vb = B.VerticalBatch.generate(args.n_per_gpu, args.dim, seed=0, row0=row0, ctx=ctx)  # resident in HBM
     if sk is not None:

@@ -55,11 +55,11 @@ typedef int innr_status;
                               * bf16 error bound, unproven queries are redone exactly. Dot metric with k <= 48; every other
                               * call is served by INNR_KNN_MFMA (innr_knn_stats.engine tells). Not chosen by INNR_KNN_AUTO. */
 
-#define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). innr_batch_knn[_dev] and
-                        * innr_batch_knn_u8[_dev] accept any k: beyond INNR_MAX_K they compute all N scores and sort them on
-                        * the device, one query at a time (the reference's own algorithm, batch.rs:754-763), and so does
-                        * innr_maxsim_topk[_multi] with its document scores. The L2 variants (filtered / reordered /
-                        * adaptive) and innr_batch_rerank* return INNR_E_UNSUPPORTED beyond it. */
+#define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). Every kNN entry point accepts
+                        * any k, like the reference: beyond INNR_MAX_K innr_batch_knn[_dev], innr_batch_knn_u8[_dev],
+                        * innr_batch_knn_filtered / _reordered compute all N scores and sort them on the device, one query
+                        * at a time (the reference's own algorithm, batch.rs:754-763), and so does innr_maxsim_topk[_multi]
+                        * with its document scores; innr_batch_rerank* sorts candidate lists longer than 256. */
 
 typedef struct innr_ctx innr_ctx;     /* one GPU: device id, stream, workspace. One per process/GPU. */
 typedef struct innr_batch innr_batch; /* device-resident VerticalBatch (PDX, dimension-major) + cached norms */
@@ -227,8 +227,9 @@ innr_status innr_maxsim_pair(const float* q, size_t nq, const float* d, size_t n
 
 /* ---- second stage of the two-stage pipeline (scalar.rs:366-368: u8 first pass, exact re-rank) --------------- */
 /* exact scores (reference arithmetic order, like innr_batch_knn's) of caller-given candidates cand[Q][kc] (global
- * indices inside this batch's range, no duplicates within a query, kc <= 256), best min(k, kc) per query in the
- * kNN functions' order (dot/cosine: score desc; L2SQ: distance asc; ties: index asc). */
+ * indices inside this batch's range, no duplicates within a query; any kc -- up to 256 candidates per query are ranked
+ * in registers, beyond that every query's candidates are sorted on the device), best min(k, kc) per query in the kNN
+ * functions' order (dot/cosine: score desc; L2SQ: distance asc; ties: index asc). */
 innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, size_t Q, size_t D, const uint64_t* cand,
                               size_t kc, size_t k, uint64_t* out_idx, float* out_score, size_t* out_k);
 innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_queries, size_t Q, size_t D,
@@ -248,6 +249,49 @@ innr_status innr_batch_prefix_view(innr_batch* parent, size_t prefix_dims, innr_
  * out: best kout per query by (score order of `metric`, index ascending). */
 innr_status innr_merge_topk_dev(innr_ctx* ctx, int metric, const uint64_t* d_idx, const float* d_score, size_t G,
                                 size_t Q, size_t kin, size_t kout, uint64_t* d_out_idx, float* d_out_score);
+
+
+/* ---- the exchange step of the sharded path, behind the boundary ------------------------------------
+ * The reference is one process, one thread (no counterpart in its source); north_star: "the corpus is range-partitioned
+ * across the 8 GPUs of one node with a final RCCL all-gather of per-shard top-k candidates over xGMI". One process per
+ * GPU; every rank holds an innr_ctx on its GPU and an innr_comm = that ctx + an RCCL communicator over all ranks. The
+ * library loads librccl at run time (the copy already mapped into the process, e.g. PyTorch's, else the system one);
+ * a failure of any RCCL call, or no RCCL library, is INNR_E_RCCL. All collectives run on the ctx stream. */
+typedef struct innr_comm innr_comm;
+#define INNR_COMM_ID_BYTES 128 /* = NCCL_UNIQUE_ID_BYTES */
+/* rank 0: a fresh id (ncclGetUniqueId) that the host ships to the other ranks by its own means (env, file, socket,
+ * torch.distributed store); then EVERY rank calls innr_comm_create with the same id -- collective, like ncclCommInitRank */
+innr_status innr_comm_unique_id(void* id_out /* [INNR_COMM_ID_BYTES] */);
+innr_status innr_comm_create(innr_ctx* ctx, const void* id, int rank, int world, innr_comm** out);
+/* or borrow a communicator the host already owns (ncclComm_t as void*; its device must be the ctx's); never destroyed here */
+innr_status innr_comm_attach(innr_ctx* ctx, void* nccl_comm, int rank, int world, innr_comm** out);
+void innr_comm_destroy(innr_comm* comm);
+int innr_comm_rank(const innr_comm* comm);
+int innr_comm_world(const innr_comm* comm);
+
+/* The exchanged unit: one BLOCK per rank = 2 + Q*k uint64:  [0] the shard's index base, [1] its vector count,
+ * [2 + q*k + r] = candidate r of query q as {low 32 bits: index local to the shard (0xFFFFFFFF = no candidate),
+ * high 32 bits: the f32 score bits} -- 8 bytes per entry (Q*k*8 bytes per rank).
+ * innr_topk_pack_dev: a shard's kNN result (d_idx global indices [Q*kin], d_score [Q*kin], kin <= k) -> its block. */
+size_t innr_topk_block_words(size_t Q, size_t k); /* = 2 + Q*k */
+innr_status innr_topk_pack_dev(innr_ctx* ctx, const uint64_t* d_idx, const float* d_score, uint64_t index_base,
+                               uint64_t shard_vectors, size_t Q, size_t kin, size_t k, uint64_t* d_block);
+/* ONE ncclAllGather of every rank's block: d_all_blocks[world][2 + Q*k] (device), in rank order */
+innr_status innr_allgather_topk_dev(innr_comm* comm, const uint64_t* d_block, size_t Q, size_t k, uint64_t* d_all_blocks);
+/* merge G gathered blocks: best min(k, total vectors) per query by (score order of `metric`, GLOBAL index ascending) --
+ * with contiguous ranges this is the reference's stable-sort tie rule (batch.rs:757) over the whole corpus.
+ * d_out_idx / d_out_score: [Q][k'] with k' = *out_k. */
+innr_status innr_merge_blocks_dev(innr_ctx* ctx, int metric, const uint64_t* d_all_blocks, size_t G, size_t Q, size_t k,
+                                  uint64_t* d_out_idx, float* d_out_score, size_t* out_k);
+/* The whole sharded call on every rank: local kNN on this rank's shard (f32 batch: `metric`; u8 code batch: the
+ * asymmetric dot, metric ignored) + pack + all-gather + merge. Queries identical on every rank (device, [Q*D]); outputs
+ * (device, sized Q*min(k, total vectors)) identical on every rank; stats describe the local search. */
+innr_status innr_sharded_knn_dev(innr_comm* comm, innr_batch* shard, int metric, const float* d_queries, size_t Q, size_t D,
+                                 size_t k, int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
+                                 innr_knn_stats* stats);
+/* the same with host buffers (what the Rust shim's sharded::Comm::knn binds; out arrays sized Q*k) */
+innr_status innr_sharded_knn(innr_comm* comm, innr_batch* shard, int metric, const float* queries, size_t Q, size_t D, size_t k,
+                             int engine, uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -118,10 +118,39 @@ SIGNATURES = {
     "innr_hamming_u8": (C.c_uint32, [_vp, _vp, _sz]),
     "innr_slot_distance_u32": (C.c_float, [_vp, _vp, _sz]),
     "innr_maxsim_pair": (C.c_int, [_vp, _sz, _vp, _sz, _sz, C.c_int, _f32p]),
+    "innr_comm_unique_id": (C.c_int, [_vp]),
+    "innr_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "innr_comm_attach": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "innr_comm_destroy": (None, [_vp]),
+    "innr_comm_rank": (C.c_int, [_vp]),
+    "innr_comm_world": (C.c_int, [_vp]),
+    "innr_topk_block_words": (_sz, [_sz, _sz]),
+    "innr_topk_pack_dev": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, _sz, _sz, _sz, _vp]),
+    "innr_allgather_topk_dev": (C.c_int, [_vp, _vp, _sz, _sz, _vp]),
+    "innr_merge_blocks_dev": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _szp]),
+    "innr_sharded_knn_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_sharded_knn": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
 }
+COMM_ID_BYTES = 128
 
 _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
+
+
+def _preload_torch_rccl() -> None:
+    """The library binds librccl at run time and prefers the copy already mapped into the process. PyTorch bundles its
+    own (torch/lib/librccl.so, loaded when torch.distributed first needs it): map that copy now, so the library's
+    communicator and torch's share one RCCL, whichever is used first. No torch installed: the system copy is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(path) and "INNR_RCCL_LIB" not in os.environ:
+            os.environ["INNR_RCCL_LIB"] = path  # load_rccl() in api.hip opens this path first
+    except Exception:
+        pass
 
 
 def _preload_torch_hip_runtime() -> None:
@@ -155,6 +184,7 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). innr_amd has no CPU fallback.")
         _preload_torch_hip_runtime()
+        _preload_torch_rccl()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = ABI drift, fail loudly
@@ -186,10 +216,21 @@ class Context:
         check(L.innr_ctx_create(int(device), C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self.stream = None  # the ctx's private stream until set_stream()
         self._children = weakref.WeakSet()  # device objects that hold a raw pointer to this ctx
 
     def set_stream(self, stream_ptr: int | None) -> None:
         check(load().innr_ctx_set_stream(self.handle, _vp(stream_ptr or 0)))
+        self.stream = int(stream_ptr or 0)  # what the library's kernels are ordered with (None until the first call)
+
+    def bind_torch_stream(self) -> None:
+        """Run the library's kernels on torch's CURRENT stream of this device, so that they are ordered with the caller's
+        torch kernels and collectives (queries produced by torch, results consumed by torch) without extra events. A
+        no-op when already bound to it. Called by every device-pointer path (innr_amd.dist)."""
+        import torch
+        cur = int(torch.cuda.current_stream(self.device).cuda_stream)
+        if getattr(self, "stream", None) != cur:
+            self.set_stream(cur)
 
     def synchronize(self) -> None:
         check(load().innr_ctx_synchronize(self.handle))

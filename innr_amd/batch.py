@@ -287,8 +287,8 @@ def knn_multi(metric: int, queries, batch: VerticalBatch, k: int, engine: int = 
 
 def batch_rerank(queries, batch: VerticalBatch, candidates, k: int, metric: int = METRIC_DOT):
     """Second stage of the two-stage pipeline (scalar.rs:366-368): exact scores of `candidates` [Q, kc] (global indices
-    inside `batch`, no duplicates per query, kc <= 256) in the reference's arithmetic order, best min(k, kc) per query in
-    the kNN functions' order. Returns (indices uint64 [Q, k'], scores float32 [Q, k'])."""
+    inside `batch`, no duplicates per query; any kc -- beyond 256 every query's candidates are sorted on the device) in the
+    reference's arithmetic order, best min(k, kc) per query in the kNN functions' order. Returns (indices uint64 [Q, k'], scores float32 [Q, k'])."""
     q = _f32(queries)
     if q.ndim == 1:
         q = q.reshape(1, -1)
@@ -322,8 +322,6 @@ def matryoshka_knn(queries, batch: VerticalBatch, prefix_dims: int, k_coarse: in
         q = q.reshape(1, -1)
     if q.shape[1] != batch.dimension():
         raise InnrPanic(f"assertion `left == right` failed\n  left: {q.shape[1]}\n right: {batch.dimension()}")
-    if k_coarse > 256:
-        raise InnrPanic("k_coarse <= 256 (innr_batch_rerank)")
     view = coarse if coarse is not None else batch.prefix(prefix_dims)
     try:
         idx, _ = knn_multi(metric, np.ascontiguousarray(q[:, :view.dimension()]), view, k_coarse, engine)

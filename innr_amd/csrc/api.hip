@@ -1,9 +1,13 @@
 // api.hip -- the extern "C" boundary (include/innr_hip.h) over the gfx950 kernels.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <rccl/rccl.h>  // types and enums only: the library is bound at run time (load_rccl), not linked
+
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -16,6 +20,15 @@
 #include "kernels_ext.h"
 #include "kernels_u8.h"
 #include "kernels_maxsim.h"
+
+namespace innr {  // sort_full.hip
+hipError_t full_sort_scratch_bytes(size_t n, size_t* bytes);
+hipError_t full_sort_scores(const float* scores, size_t n, bool smaller_is_better, uint64_t* keys, uint64_t* sorted,
+                            void* scratch, size_t scratch_bytes, hipStream_t stream, const uint8_t* mask = nullptr);
+hipError_t segmented_sort_scratch_bytes(size_t nseg, size_t len, size_t* bytes);
+hipError_t segmented_sort_keys(const uint64_t* keys, uint64_t* sorted, size_t nseg, size_t len, uint32_t* off, void* scratch,
+                               size_t scratch_bytes, hipStream_t stream);
+}  // namespace innr
 
 namespace innr {
 
@@ -55,6 +68,11 @@ struct DevBuf {
 using namespace innr;
 
 struct innr_ctx {
+    // One call at a time per context: the workspace below (grow-by-free DevBufs, the pinned bump allocator, `pending`,
+    // the flags buffer, ev[]) is shared by every entry point, so each one holds this lock for its whole duration
+    // (CtxGuard). Recursive: host-pointer entry points call their _dev counterparts.
+    std::recursive_mutex mu;
+    int depth = 0;  // nesting of CtxGuards on the owning thread
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -92,7 +110,10 @@ struct innr_ctx {
     DevBuf seed_score;
     DevBuf misc;
     DevBuf q_bf16;     // bf16 filter engine: K-packed bf16 queries
-    DevBuf redo_q, redo_idx, redo_sc, redo_map;  // bf16 filter engine: unproven queries, redone as ONE batch on the f32 engine
+    struct RedoBufs {
+        DevBuf q, idx, sc, map, qn;
+    } redo[2];  // unproven queries, gathered and redone as ONE batch; [1]: the batch's own unproven queries (redo_batch)
+    DevBuf q_pad;      // exact engine: a ragged tail of 2-3 / 5-7 queries padded with zero rows to a 4- / 8-query pass
     DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
     DevBuf sort_keys;  // [2][N] composites: unsorted, sorted
     DevBuf sort_tmp;   // radix sort scratch
@@ -165,6 +186,33 @@ static innr_status bind_device(innr_ctx* ctx) {
     return INNR_OK;
 }
 
+// Serialises the entry points of one context and, when the outermost entry point leaves with device->host copies still
+// queued (an error return between a copy_out and its ctx_sync), cancels them: their destinations may be stack variables
+// of frames that are gone, and the next successful ctx_sync must not deliver into them.
+struct CtxGuard {
+    innr_ctx* c;
+    explicit CtxGuard(innr_ctx* ctx) : c(ctx) {
+        if (c) {
+            c->mu.lock();
+            ++c->depth;
+        }
+    }
+    ~CtxGuard() {
+        if (!c) return;
+        if (--c->depth == 0 && (!c->pending.empty() || c->pin_in_off || c->pin_out_off)) {
+            (void)hipStreamSynchronize(c->stream);  // the staged copies still target the pinned area: let them land
+            c->pending.clear();
+            c->pin_in_off = c->pin_out_off = 0;
+        }
+        c->mu.unlock();
+    }
+    CtxGuard(const CtxGuard&) = delete;
+    CtxGuard& operator=(const CtxGuard&) = delete;
+};
+#define INNR_ENTER(ctxp)            \
+    ::innr::CtxGuard _guard(ctxp);  \
+    INNR_TRY(::innr::bind_device(ctxp))
+
 static innr_status alloc_batch(innr_ctx* ctx, size_t N, size_t D, innr_batch** out) {
     if (!ctx || !out) {
         set_error("null ctx/out");
@@ -174,7 +222,7 @@ static innr_status alloc_batch(innr_ctx* ctx, size_t N, size_t D, innr_batch** o
         set_error("corpus shard too large for u32 device indices (N=%zu, D=%zu)", N, D);
         return INNR_E_UNSUPPORTED;
     }
-    INNR_TRY(bind_device(ctx));
+    INNR_ENTER(ctx);
     innr_batch* b = new (std::nothrow) innr_batch();
     if (!b) return INNR_E_OOM;
     b->ctx = ctx;
@@ -354,25 +402,42 @@ static innr_status knn_exact_range(innr_batch* b_full, int metric, const float* 
     size_t done = 0;
     while (done < nq) {
         const size_t rem = nq - done;
-        const uint32_t qb = rem >= 8 ? 8 : (rem >= 4 ? 4 : 1);
-        const uint32_t groups = qb == 8 ? (uint32_t)std::min<size_t>(rem / 8, max_groups) : 1u;
-        const uint32_t nql = qb * groups;  // queries in this launch
+        // One corpus pass serves 8, 4 or 1 queries. A ragged tail of 5-7 (2-3) queries takes ONE 8- (4-) query pass with
+        // zero rows as padding instead of several smaller passes (2 queries: 5.5 ms instead of 2 x 5.2 at 10M x 768).
+        const uint32_t qb = rem >= 5 ? 8 : (rem >= 2 ? 4 : 1);
+        const uint32_t groups = (qb == 8 && rem >= 8) ? (uint32_t)std::min<size_t>(rem / 8, max_groups) : 1u;
+        const uint32_t nql = qb * groups;                               // query slots of this launch
+        const uint32_t nreal = (uint32_t)std::min<size_t>(nql, rem);    // ... of which real queries
         INNR_TRY(c->lists.ensure(nslots * nql * cap * sizeof(uint64_t)));
         INNR_TRY(c->counts.ensure(nslots * nql * sizeof(uint32_t)));
         const float* q = dQ + (q0 + done) * ldq;
         const float* qn = dQn ? dQn + q0 + done : nullptr;
+        if (nreal < nql) {  // pad: rows [nreal, nql) are zero queries (and zero norms) whose results are dropped
+            const size_t row_bytes = ldq * sizeof(float);
+            INNR_TRY(c->q_pad.ensure(nql * row_bytes + nql * sizeof(float) + 16));
+            INNR_HIP_CHECK(hipMemsetAsync(c->q_pad.p, 0, nql * row_bytes + nql * sizeof(float), c->stream));
+            if (b->D)
+                INNR_HIP_CHECK(hipMemcpy2DAsync(c->q_pad.p, row_bytes, q, row_bytes, b->D * sizeof(float), nreal,
+                                                hipMemcpyDeviceToDevice, c->stream));
+            float* qn_pad = reinterpret_cast<float*>(c->q_pad.as<char>() + nql * row_bytes);
+            if (qn) {
+                INNR_HIP_CHECK(hipMemcpyAsync(qn_pad, qn, nreal * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                qn = qn_pad;
+            }
+            q = c->q_pad.as<float>();
+        }
         switch (qb) {
             case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext, groups)); break;
             case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
             default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
         }
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
-        const uint32_t total = nql * (uint32_t)kout;
+        const uint32_t total = nreal * (uint32_t)kout;
         emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
-            c->sel.as<uint64_t>(), KP, nql, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
+            c->sel.as<uint64_t>(), KP, nreal, (uint32_t)kout, l2, b->index_base, d_out_idx + (q0 + done) * kout,
             d_out_score + (q0 + done) * kout);
         INNR_HIP_CHECK(hipGetLastError());
-        done += nql;
+        done += nreal;
     }
     return INNR_OK;
 }
@@ -513,6 +578,64 @@ __global__ void scatter_results_kernel(const uint64_t* __restrict__ idx, const f
     out_sc[o] = sc[t];
 }
 
+__global__ void gather_f32_kernel(const float* __restrict__ src, const uint32_t* __restrict__ map, uint32_t n, float* __restrict__ dst) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[map[t]];
+}
+
+static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* dQn,
+                            uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
+                            float* gemm_ms, bool bf16 = false, uint32_t kp_force = 0, int level = 0);
+
+// Queries whose margin proof failed (`redo`: their indices, ascending): gathered into ONE contiguous block and redone
+// together -- on the exact engine, 8 queries per corpus pass (via_gemm_kp == 0), or once more on the f32 GEMM engine
+// with lists of via_gemm_kp candidates (whose own unproven queries then take the exact engine) -- and scattered back.
+// One exact corpus scan PER QUERY made near-tie data cost ~5 ms per query at 10M x 768; a pass of 8 costs 6.6 ms.
+// qn_all: per-query norms of the whole batch (cosine; may be null otherwise).
+static innr_status redo_batch(innr_batch* b, int metric, const float* dQ, const float* qn_all,
+                              const std::vector<uint32_t>& redo, size_t kout, uint64_t* d_out_idx, float* d_out_score,
+                              uint32_t via_gemm_kp, int level) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size(), D = b->D;
+    if (nr == 0) return INNR_OK;
+    if (level < 0 || level > 1) {
+        set_error("internal: redo_batch nesting %d", level);
+        return INNR_E_HIP;
+    }
+    innr_ctx::RedoBufs& rb = c->redo[level];  // the nested GEMM pass (level + 1) reads these while filling its own set
+    INNR_TRY(rb.map.ensure(nr * sizeof(uint32_t)));
+    INNR_TRY(rb.q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
+    INNR_TRY(rb.qn.ensure(nr * sizeof(float)));
+    INNR_TRY(rb.idx.ensure(nr * kout * sizeof(uint64_t)));
+    INNR_TRY(rb.sc.ensure(nr * kout * sizeof(float)));
+    INNR_HIP_CHECK(hipMemcpyAsync(rb.map.p, redo.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));  // redo is a pageable host vector
+    const uint32_t* map = rb.map.as<uint32_t>();
+    if (D) {
+        gather_rows_kernel<<<(unsigned)((nr * D + 255) / 256), 256, 0, c->stream>>>(dQ, map, (uint32_t)nr, (uint32_t)D,
+                                                                                rb.q.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    const float* qn = nullptr;
+    if (qn_all) {
+        gather_f32_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>(qn_all, map, (uint32_t)nr, rb.qn.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+        qn = rb.qn.as<float>();
+    }
+    if (via_gemm_kp) {
+        uint32_t nf2 = 0, kept2 = 0;
+        float ms2 = 0.0f;
+        INNR_TRY(knn_mfma(b, metric, rb.q.as<float>(), nr, kout, qn, rb.idx.as<uint64_t>(), rb.sc.as<float>(), &nf2, &kept2,
+                          &ms2, false, via_gemm_kp, level + 1));
+    } else {
+        INNR_TRY(knn_exact_range(b, metric, rb.q.as<float>(), D, qn, 0, nr, kout, rb.idx.as<uint64_t>(), rb.sc.as<float>()));
+    }
+    scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(
+        rb.idx.as<uint64_t>(), rb.sc.as<float>(), map, (uint32_t)nr, (uint32_t)kout, d_out_idx, d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
 static uint32_t bf16_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 64) / 32); }  // K-steps of 32, even
 
 static innr_status ensure_bf16_corpus(innr_batch* b) {
@@ -557,7 +680,7 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, const uint
 
 static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* /*dQn*/,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
-                            float* gemm_ms, bool bf16 = false) {
+                            float* gemm_ms, bool bf16, uint32_t kp_force, int level) {
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
@@ -566,6 +689,10 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     const bool use_bf16 = bf16 && !cos && !l2 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
                           (b->max_norm - b->max_norm == 0.0f);
     GemmPlan p = plan_gemm(b, Q, kout, use_bf16 ? 8 : 0, !cos && !l2);
+    if (kp_force && !use_bf16 && kp_force >= p.KP && kp_force <= 256) {  // second attempt of redo_batch: longer lists
+        p.KP = kp_force;
+        p.cap = (uint32_t)cand_cap((int)p.KP);
+    }
     if (use_bf16) {
         p.KP = pick_kp(4 * kout + 64, 0);
         p.cap = (uint32_t)cand_cap((int)p.KP);
@@ -665,49 +792,39 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     // bf16 products / sums below the normal range may be flushed to zero: the bound E must dwarf that, else redo exactly
     for (size_t q = 0; q < qn_host.size(); ++q)
         if (!(qn_host[q] * b->max_norm >= 1e-25f)) fb[q] = 1;
+    // A non-finite corpus value (max_norm is then NaN or inf) voids every error bound -- for cosine too, whose bound does
+    // not carry max_norm: NaN * 0 approximations can differ from the reference's 0.0 (batch.rs:722) by more than E.
+    if (!(b->max_norm - b->max_norm == 0.0f))
+        for (size_t q = 0; q < Q; ++q) fb[q] = 1;
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
-    uint32_t nf = 0;
-    if (use_bf16) {
-        // The bf16 bound is ~2^15 times the f32 one: on data with small gaps at the cut many proofs fail. Those queries
-        // go through the f32 GEMM engine as ONE batch (its own proof, and the exact engine behind it) instead of one
-        // exact corpus scan each.
-        std::vector<uint32_t> redo;
-        for (size_t q = 0; q < Q; ++q)
-            if (fb[q]) redo.push_back((uint32_t)q);
-        if (redo.size() >= 4) {
-            const size_t nr = redo.size(), D = b->D;
-            INNR_TRY(c->redo_map.ensure(nr * sizeof(uint32_t)));
-            INNR_TRY(c->redo_q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
-            INNR_TRY(c->redo_idx.ensure(nr * kout * sizeof(uint64_t)));
-            INNR_TRY(c->redo_sc.ensure(nr * kout * sizeof(float)));
-            INNR_HIP_CHECK(hipMemcpyAsync(c->redo_map.p, redo.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            INNR_HIP_CHECK(hipStreamSynchronize(c->stream));  // redo is a pageable host vector
-            if (D) {
-                gather_rows_kernel<<<(unsigned)((nr * D + 255) / 256), 256, 0, c->stream>>>(dQ, c->redo_map.as<uint32_t>(), (uint32_t)nr,
-                                                                                        (uint32_t)D, c->redo_q.as<float>());
-                INNR_HIP_CHECK(hipGetLastError());
-            }
-            uint32_t nf2 = 0, kept2 = 0;
-            float ms2 = 0.0f;
-            INNR_TRY(knn_mfma(b, metric, c->redo_q.as<float>(), nr, kout, nullptr, c->redo_idx.as<uint64_t>(), c->redo_sc.as<float>(),
-                              &nf2, &kept2, &ms2, false));
-            scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(
-                c->redo_idx.as<uint64_t>(), c->redo_sc.as<float>(), c->redo_map.as<uint32_t>(), (uint32_t)nr, (uint32_t)kout, d_out_idx,
-                d_out_score);
-            INNR_HIP_CHECK(hipGetLastError());
-            *nfallback = (uint32_t)nr;
-            *kept = p.KP;
-            return INNR_OK;
+    std::vector<uint32_t> redo;
+    for (size_t q = 0; q < Q; ++q)
+        if (fb[q]) redo.push_back((uint32_t)q);  // margin proof failed (near-tie at the cut, or non-finite scores)
+    *nfallback = (uint32_t)redo.size();
+    *kept = p.KP;
+    if (!redo.empty()) {
+        const float* qn_all = cos ? c->q_norm.as<float>() : nullptr;
+        uint32_t via = 0;
+        if (use_bf16 && redo.size() >= 4) {
+            // The bf16 bound is ~2^15 times the f32 one: on data with small gaps at the cut many proofs fail. Those
+            // queries go through the f32 GEMM engine as one batch (its own proof, and the exact engine behind it).
+            via = pick_kp(kout, 16);
+        } else if (!use_bf16 && !kp_force && p.KP < 256 && redo.size() >= 16 && redo.size() * 4 <= Q &&
+                   !getenv("INNR_GEMM_NO_KP_RETRY")) {
+            // A minority of the batch failed: isolated clusters of near-equal scores (duplicates, quantised data), which
+            // lists of 256 candidates usually swallow -- one more GEMM pass over those queries instead of an exact scan
+            // for each 8 of them. When most of the batch fails the data is degenerate (the reference example's LCG
+            // rows: hundreds of vectors within 2E of the k-th): straight to the exact engine.
+            via = 256;
+        }
+        if (redo.size() == 1 && !via) {
+            INNR_TRY(knn_exact_range(b, metric, dQ, b->D, qn_all, redo[0], 1, kout, d_out_idx, d_out_score));
+        } else {
+            // at most two levels: a second GEMM attempt (kp_force set, never bf16) sends its own failures to the exact engine
+            INNR_TRY(redo_batch(b, metric, dQ, qn_all, redo, kout, d_out_idx, d_out_score, level == 0 ? via : 0u, level));
         }
     }
-    for (size_t q = 0; q < Q; ++q) {
-        if (!fb[q]) continue;
-        ++nf;  // margin proof failed (near-tie at the cut, or non-finite scores): redo this query exactly
-        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), q, 1, kout, d_out_idx, d_out_score));
-    }
-    *nfallback = nf;
-    *kept = p.KP;
     if (bf16 && !use_bf16) *gemm_ms = -*gemm_ms;  // told apart by the caller: the f32 engine served this call
     return INNR_OK;
 }
@@ -779,7 +896,9 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->redo_q, &c->redo_idx, &c->redo_sc, &c->redo_map};
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad,
+                      &c->redo[0].q, &c->redo[0].idx, &c->redo[0].sc, &c->redo[0].map, &c->redo[0].qn,
+                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)
@@ -790,7 +909,7 @@ void innr_ctx_destroy(innr_ctx* c) {
 
 innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
     if (!c) return INNR_E_BAD_ARG;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     INNR_HIP_CHECK(ctx_sync(c));
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream (what torch uses unless told otherwise)
@@ -800,7 +919,7 @@ innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
 
 innr_status innr_ctx_synchronize(innr_ctx* c) {
     if (!c) return INNR_E_BAD_ARG;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
@@ -811,6 +930,8 @@ innr_status innr_batch_upload_colmajor(innr_ctx* ctx, const float* data, size_t 
         set_error("data is null");
         return INNR_E_BAD_ARG;
     }
+    if (!ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch(ctx, N, D, &b));
     if (N && D) {
@@ -832,6 +953,8 @@ innr_status innr_batch_upload_rowmajor(innr_ctx* ctx, const float* rows, size_t 
         set_error("rows is null");
         return INNR_E_BAD_ARG;
     }
+    if (!ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch(ctx, N, D, &b));
     if (N && D) {
@@ -871,6 +994,8 @@ innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator
         set_error("unknown generator %d", generator);
         return INNR_E_BAD_ARG;
     }
+    if (!ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch(ctx, N, D, &b));
     if (N && D) {
@@ -898,6 +1023,7 @@ innr_status innr_batch_generate(innr_ctx* ctx, size_t N, size_t D, int generator
 
 void innr_batch_free(innr_batch* b) {
     if (!b) return;
+    CtxGuard _guard(b->ctx);
     if (b->ctx) {
         (void)hipSetDevice(b->ctx->device);
         (void)ctx_sync(b->ctx);
@@ -917,7 +1043,7 @@ innr_status innrdbg_last_selection(innr_batch* b, size_t Q, size_t KP, uint64_t*
                                    float* info /* [0]=max_norm */) {
     if (!b) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     INNR_HIP_CHECK(hipMemcpy(sel, c->sel.p, Q * KP * sizeof(uint64_t), hipMemcpyDeviceToHost));
     INNR_HIP_CHECK(hipMemcpy(cnt, c->sel_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost));
     INNR_HIP_CHECK(hipMemcpy(qnorm, c->q_norm.p, Q * sizeof(float), hipMemcpyDeviceToHost));
@@ -934,7 +1060,7 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     }
     if (!b || !queries || !out || D != b->D || Q == 0 || b->N == 0) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const bool cos = metric == INNR_METRIC_COSINE;
     const GemmPlan p = plan_gemm(b, Q, 1, /*waves=*/4);
     INNR_TRY(ensure_norms(b));
@@ -971,14 +1097,62 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
     }
     *out_k = 0;
     if (b->N == 0 || k == 0 || Q == 0 || kc == 0) return INNR_OK;
-    if (kc > 256) {
-        set_error("rerank: at most 256 candidates per query (got %zu)", kc);
-        return INNR_E_UNSUPPORTED;
-    }
     if (!d_queries || !d_cand || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     const size_t kout = std::min(k, kc);
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
+    if (kc > 256) {
+        // More candidates per query than a candidate list holds: exact scores of all of them (one thread per candidate,
+        // the reference's arithmetic order), then every query's kc composites sorted best-first in one segmented radix
+        // sort -- the reference's "score, stable sort, truncate" (scalar.rs:366-368 on top of batch.rs:754-763).
+        if (Q * kc > 0x7fffffffull) {
+            set_error("rerank: Q * candidates = %zu exceeds 2^31 - 1", Q * kc);
+            return INNR_E_UNSUPPORTED;
+        }
+        size_t tmp_bytes = 0;
+        INNR_HIP_CHECK(segmented_sort_scratch_bytes(Q, kc, &tmp_bytes));
+        INNR_TRY(c->sort_keys.ensure(2 * Q * kc * sizeof(uint64_t)));
+        INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        INNR_TRY(c->q_norm.ensure(Q * sizeof(float)));
+        INNR_TRY(c->misc.ensure((Q + 1) * sizeof(uint32_t) + 64));
+        INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+        if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
+        query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+                                                                           c->q_norm.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+        uint32_t* bad = c->flags.as<uint32_t>() + 65;
+        uint64_t* keys = c->sort_keys.as<uint64_t>();
+        const unsigned nb = (unsigned)((Q * kc + 255) / 256);
+        const int met = metric == INNR_METRIC_COSINE ? 1 : (metric == INNR_METRIC_L2SQ ? 2 : 0);
+        if (met == 1)
+            rerank_scores_kernel<1><<<nb, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)D, d_queries, b->norms,
+                                                              c->q_norm.as<float>(), d_cand, (uint32_t)Q, (uint32_t)kc,
+                                                              b->index_base, keys, bad);
+        else if (met == 2)
+            rerank_scores_kernel<2><<<nb, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)D, d_queries, b->norms,
+                                                              c->q_norm.as<float>(), d_cand, (uint32_t)Q, (uint32_t)kc,
+                                                              b->index_base, keys, bad);
+        else
+            rerank_scores_kernel<0><<<nb, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)D, d_queries, b->norms,
+                                                              c->q_norm.as<float>(), d_cand, (uint32_t)Q, (uint32_t)kc,
+                                                              b->index_base, keys, bad);
+        INNR_HIP_CHECK(hipGetLastError());
+        INNR_HIP_CHECK(segmented_sort_keys(keys, keys + Q * kc, Q, kc, c->misc.as<uint32_t>(), c->sort_tmp.p, tmp_bytes, c->stream));
+        const uint32_t total = (uint32_t)(Q * kout);
+        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(keys + Q * kc, (uint32_t)kc, (uint32_t)Q, (uint32_t)kout,
+                                                                        met == 2, b->index_base, d_out_idx, d_out_score);
+        INNR_HIP_CHECK(hipGetLastError());
+        uint32_t hbad = 0;
+        INNR_HIP_CHECK(copy_out(c, &hbad, bad, 4));
+        INNR_HIP_CHECK(ctx_sync(c));
+        if (hbad) {
+            set_error("rerank: a candidate index lies outside this batch's range [%llu, %llu)",
+                      (unsigned long long)b->index_base, (unsigned long long)(b->index_base + b->N));
+            return INNR_E_BAD_ARG;
+        }
+        *out_k = kout;
+        return INNR_OK;
+    }
     const uint32_t KP = pick_kp(kc, 0);  // 32..256
     INNR_TRY(c->sel.ensure(Q * KP * sizeof(uint64_t)));
     INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
@@ -1032,7 +1206,7 @@ innr_status innr_batch_rerank(innr_batch* b, int metric, const float* queries, s
     if (b->N == 0 || k == 0 || Q == 0 || kc == 0) return (b->V && D != b->D) ? (set_error("dimension mismatch: query.len()=%zu, batch.dimension=%zu", D, b->D), INNR_E_DIM_MISMATCH) : INNR_OK;
     if (!queries || !cand || !out_idx || !out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const size_t kout = std::min(k, kc);
     INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(Q * (kout + kc) * sizeof(uint64_t)));
@@ -1070,7 +1244,7 @@ innr_status innr_batch_download_colmajor(innr_batch* b, float* out) {
     }
     if (!b || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
     if (b->N == 0 || b->D == 0) return INNR_OK;
-    INNR_TRY(bind_device(b->ctx));
+    INNR_ENTER(b->ctx);
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), b->V, b->ldN * sizeof(float), b->N * sizeof(float),
                                     b->D, hipMemcpyDeviceToHost, b->ctx->stream));
     INNR_HIP_CHECK(ctx_sync(b->ctx));
@@ -1091,7 +1265,7 @@ innr_status innr_batch_norms(innr_batch* b, float* out) {
     }
     if (!b || (!out && b->N)) return INNR_E_BAD_ARG;
     if (b->N == 0) return INNR_OK;
-    INNR_TRY(bind_device(b->ctx));
+    INNR_ENTER(b->ctx);
     INNR_TRY(ensure_norms(b));
     INNR_HIP_CHECK(copy_out(b->ctx, out, b->norms, b->N * sizeof(float)));
     INNR_HIP_CHECK(ctx_sync(b->ctx));
@@ -1114,7 +1288,7 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
     if (b->N == 0) return INNR_OK;
     if (!out || (!q && D)) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const size_t ldq = round_up(D ? D : 1, 4);
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
     INNR_TRY(c->q_norm.ensure(sizeof(float)));
@@ -1160,11 +1334,6 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
 
 }  // extern "C"
 
-namespace innr {  // sort_full.hip
-hipError_t full_sort_scratch_bytes(size_t n, size_t* bytes);
-hipError_t full_sort_scores(const float* scores, size_t n, bool smaller_is_better, uint64_t* keys, uint64_t* sorted,
-                            void* scratch, size_t scratch_bytes, hipStream_t stream);
-}  // namespace innr
 
 // k > INNR_MAX_K: more results than a candidate list holds. The reference's own algorithm, on the device: all N
 // scores of one query (scan_scores_kernel: the reference-order arithmetic the exact engine uses), a full sort of
@@ -1246,7 +1415,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     const size_t kout = std::min(k, b->N);              // batch.rs:395, 752
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
@@ -1309,7 +1478,7 @@ innr_status innr_batch_knn(innr_batch* b, int metric, const float* queries, size
     if (b->N == 0 || k == 0 || Q == 0) return INNR_OK;
     if (!queries && D) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const size_t kout = std::min(k, b->N);
     INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
@@ -1334,7 +1503,7 @@ static innr_status alloc_batch_u8(innr_ctx* ctx, size_t N, size_t D, float alpha
         set_error("u8 corpus shard too large (N=%zu, D=%zu)", N, D);
         return INNR_E_UNSUPPORTED;
     }
-    INNR_TRY(bind_device(ctx));
+    INNR_ENTER(ctx);
     innr_batch* b = new (std::nothrow) innr_batch();
     if (!b) return INNR_E_OOM;
     b->ctx = ctx;
@@ -1358,7 +1527,8 @@ static innr_status alloc_batch_u8(innr_ctx* ctx, size_t N, size_t D, float alpha
 
 innr_status innr_batch_upload_u8(innr_ctx* ctx, const uint8_t* codes, size_t N, size_t D, float alpha, float offset,
                                  innr_batch** out) {
-    if (!codes && N * D) return INNR_E_BAD_ARG;
+    if ((!codes && N * D) || !ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch_u8(ctx, N, D, alpha, offset, &b));
     if (N && D) {
@@ -1387,6 +1557,8 @@ innr_status innr_batch_upload_u8(innr_ctx* ctx, const uint8_t* codes, size_t N, 
 
 innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t seed, uint64_t row0, float alpha,
                                    float offset, innr_batch** out) {
+    if (!ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch_u8(ctx, N, D, alpha, offset, &b));
     if (N && D) {
@@ -1413,6 +1585,7 @@ innr_status innr_batch_quantize_u8(innr_batch* src, float alpha, float offset, i
         return INNR_E_BAD_ARG;
     }
     innr_ctx* ctx = src->ctx;
+    INNR_ENTER(ctx);
     innr_batch* b = nullptr;
     INNR_TRY(alloc_batch_u8(ctx, src->N, src->D, alpha, offset, &b));
     if (src->N && src->D) {
@@ -1464,7 +1637,7 @@ innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int
         return INNR_E_BAD_ARG;
     }
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     *out_any = 0;
     *out_min = 0.0f;
     *out_max = 0.0f;
@@ -1488,7 +1661,7 @@ innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int
 innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out) {
     if (!b || !b->C8 || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
     if (b->N == 0 || b->D == 0) return INNR_OK;
-    INNR_TRY(bind_device(b->ctx));
+    INNR_ENTER(b->ctx);
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N, b->C8, b->ldN, b->N, b->D, hipMemcpyDeviceToHost, b->ctx->stream));
     INNR_HIP_CHECK(ctx_sync(b->ctx));
     return INNR_OK;
@@ -1512,7 +1685,7 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
     if (b->N == 0) return INNR_OK;
     if (!out || (!q && D)) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const size_t ldq = round_up(D ? D : 1, 4);
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
     INNR_TRY(c->q_norm.ensure(2 * sizeof(float)));
@@ -1567,23 +1740,67 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
     max_groups = std::min<size_t>(max_groups, 65535);
     size_t done = 0;
     while (done < nq) {
-        const uint32_t qb = (nq - done) >= 4 ? 4 : 1;
-        const uint32_t groups = qb == 4 ? (uint32_t)std::min<size_t>((nq - done) / 4, max_groups) : 1u;
+        const size_t rem = nq - done;
+        const uint32_t qb = rem >= 2 ? 4 : 1;  // 2-3 queries: one 4-query pass padded with zero rows (cf. knn_exact_range)
+        const uint32_t groups = (qb == 4 && rem >= 4) ? (uint32_t)std::min<size_t>(rem / 4, max_groups) : 1u;
         const uint32_t nql = qb * groups;
+        const uint32_t nreal = (uint32_t)std::min<size_t>(nql, rem);
         INNR_TRY(c->lists.ensure(nslots * nql * cap * sizeof(uint64_t)));
         INNR_TRY(c->counts.ensure(nslots * nql * sizeof(uint32_t)));
         const float* q = dQ + (q0 + done) * ldq;
         const float* qs = qsum + q0 + done;
+        if (nreal < nql) {
+            const size_t row_bytes = ldq * sizeof(float);
+            INNR_TRY(c->q_pad.ensure(nql * row_bytes + nql * sizeof(float) + 16));
+            INNR_HIP_CHECK(hipMemsetAsync(c->q_pad.p, 0, nql * row_bytes + nql * sizeof(float), c->stream));
+            if (b->D)
+                INNR_HIP_CHECK(hipMemcpy2DAsync(c->q_pad.p, row_bytes, q, row_bytes, b->D * sizeof(float), nreal,
+                                                hipMemcpyDeviceToDevice, c->stream));
+            float* qs_pad = reinterpret_cast<float*>(c->q_pad.as<char>() + nql * row_bytes);
+            INNR_HIP_CHECK(hipMemcpyAsync(qs_pad, qs, nreal * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            q = c->q_pad.as<float>();
+            qs = qs_pad;
+        }
         if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups));
         else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps));
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
-        const uint32_t total = nql * (uint32_t)kout;
-        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, nql, (uint32_t)kout, false,
+        const uint32_t total = nreal * (uint32_t)kout;
+        emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, nreal, (uint32_t)kout, false,
                                                                         b->index_base, d_out_idx + (q0 + done) * kout,
                                                                         d_out_score + (q0 + done) * kout);
         INNR_HIP_CHECK(hipGetLastError());
-        done += nql;
+        done += nreal;
     }
+    return INNR_OK;
+}
+
+// unproven queries of the u8 GEMM / int8 engines: gathered and redone together on the exact engine (4 per corpus pass)
+static innr_status redo_batch_u8(innr_batch* b, const float* dQ, const float* qsum, const std::vector<uint32_t>& redo,
+                                 size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size(), D = b->D;
+    if (nr == 0) return INNR_OK;
+    if (nr == 1) return knn_u8_exact_range(b, dQ, D, qsum, redo[0], 1, kout, d_out_idx, d_out_score);
+    innr_ctx::RedoBufs& rb = c->redo[0];
+    INNR_TRY(rb.map.ensure(nr * sizeof(uint32_t)));
+    INNR_TRY(rb.q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
+    INNR_TRY(rb.qn.ensure(nr * sizeof(float)));
+    INNR_TRY(rb.idx.ensure(nr * kout * sizeof(uint64_t)));
+    INNR_TRY(rb.sc.ensure(nr * kout * sizeof(float)));
+    INNR_HIP_CHECK(hipMemcpyAsync(rb.map.p, redo.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));  // redo is a pageable host vector
+    const uint32_t* map = rb.map.as<uint32_t>();
+    if (D) {
+        gather_rows_kernel<<<(unsigned)((nr * D + 255) / 256), 256, 0, c->stream>>>(dQ, map, (uint32_t)nr, (uint32_t)D,
+                                                                                rb.q.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    gather_f32_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>(qsum, map, (uint32_t)nr, rb.qn.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(knn_u8_exact_range(b, rb.q.as<float>(), D, rb.qn.as<float>(), 0, nr, kout, rb.idx.as<uint64_t>(), rb.sc.as<float>()));
+    scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(
+        rb.idx.as<uint64_t>(), rb.sc.as<float>(), map, (uint32_t)nr, (uint32_t)kout, d_out_idx, d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
 
@@ -1629,15 +1846,12 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
     INNR_HIP_CHECK(ctx_sync(c));
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
-    uint32_t nf = 0;
-    for (size_t q = 0; q < Q; ++q) {
-        if (!fb[q]) continue;
-        ++nf;
-        INNR_TRY(knn_u8_exact_range(b, dQ, b->D, qsum, q, 1, kout, d_out_idx, d_out_score));
-    }
-    *nfallback = nf;
+    std::vector<uint32_t> redo;
+    for (size_t q = 0; q < Q; ++q)
+        if (fb[q]) redo.push_back((uint32_t)q);
+    *nfallback = (uint32_t)redo.size();
     *kept = p.KP;
-    return INNR_OK;
+    return redo_batch_u8(b, dQ, qsum, redo, kout, d_out_idx, d_out_score);
 }
 
 innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t Q, size_t D, size_t k, int engine,
@@ -1651,7 +1865,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     const size_t kout = std::min(k, b->N);  // scalar.rs:381
     if (!d_queries || !d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     INNR_TRY(c->q_norm.ensure(2 * round_up(Q, kBQmax) * sizeof(float)));
@@ -1696,7 +1910,7 @@ innr_status innr_batch_knn_u8(innr_batch* b, const float* queries, size_t Q, siz
     if (Q == 0) return INNR_OK;
     if (!queries && D) return INNR_E_BAD_ARG;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     const size_t kout = std::min(k, b->N);
     INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(Q * kout * sizeof(uint64_t)));
@@ -1729,7 +1943,7 @@ static innr_status alloc_docs(innr_ctx* ctx, size_t ndocs, size_t T, size_t dim,
         set_error("maxsim corpus limits: docs < 2^32, dim <= 1024, T <= 65535 (got %zu, %zu, %zu)", ndocs, dim, T);
         return INNR_E_UNSUPPORTED;
     }
-    INNR_TRY(bind_device(ctx));
+    INNR_ENTER(ctx);
     innr_docs* d = new (std::nothrow) innr_docs();
     if (!d) return INNR_E_OOM;
     d->ctx = ctx;
@@ -1749,7 +1963,8 @@ static innr_status alloc_docs(innr_ctx* ctx, size_t ndocs, size_t T, size_t dim,
 
 innr_status innr_maxsim_upload(innr_ctx* ctx, const float* tokens, const uint32_t* doc_len, size_t ndocs, size_t T,
                                size_t dim, innr_docs** out) {
-    if (!tokens && ndocs * T * dim) return INNR_E_BAD_ARG;
+    if ((!tokens && ndocs * T * dim) || !ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_docs* d = nullptr;
     INNR_TRY(alloc_docs(ctx, ndocs, T, dim, &d));
     hipError_t e = hipSuccess;
@@ -1769,6 +1984,8 @@ innr_status innr_maxsim_upload(innr_ctx* ctx, const float* tokens, const uint32_
 
 innr_status innr_maxsim_generate(innr_ctx* ctx, size_t ndocs, size_t T, size_t dim, uint64_t seed, uint64_t row0,
                                  innr_docs** out) {
+    if (!ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
     innr_docs* d = nullptr;
     INNR_TRY(alloc_docs(ctx, ndocs, T, dim, &d));
     const size_t ntok = ndocs * T;
@@ -1788,6 +2005,7 @@ innr_status innr_maxsim_generate(innr_ctx* ctx, size_t ndocs, size_t T, size_t d
 
 void innr_docs_free(innr_docs* d) {
     if (!d) return;
+    CtxGuard _guard(d->ctx);
     if (d->ctx) {
         (void)hipSetDevice(d->ctx->device);
         (void)ctx_sync(d->ctx);
@@ -1881,7 +2099,7 @@ static innr_status maxsim_scores_dev(innr_docs* d, int cosine, const float* qtok
 
 innr_status innr_maxsim_scores(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, float* out) {
     if (!d || (!out && d->ndocs) || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
-    INNR_TRY(bind_device(d->ctx));
+    INNR_ENTER(d->ctx);
     INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, dim));
     if (d->ndocs) {
         INNR_HIP_CHECK(copy_out(d->ctx, out, d->ctx->scores.p, d->ndocs * sizeof(float)));
@@ -1983,14 +2201,17 @@ static innr_status maxsim_approx(innr_docs* d, int cosine, const float* const* q
     }
     INNR_TRY(c->scores.ensure((size_t)nqr * d->ndocs * sizeof(float)));
     INNR_TRY(c->q_kmajor.ensure((size_t)nqr * kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));
-    INNR_TRY(c->misc.ensure(16384));  // [0,4K) norm scratch, [4K,8K) per-pass token counts, [8K,..) candidate ids / exact scores
+    // [0,8K) norm scratch, [8K,16K) candidate ids / exact scores (maxsim_post), [16K,..) per-pass token counts: 16 bytes
+    // per pass of kMsQ query tokens -- sized from the pass count, a long query must not run into its neighbours
+    const size_t npass = Tq_pad / kMsQ;
+    INNR_TRY(c->misc.ensure(16384 + npass * 16 + 64));
     float* qB = c->q_kmajor.as<float>();
     float* approx = c->scores.as<float>();
     const size_t qb_stride = dim * 32;  // floats per packed query: [dim/8][64][4]
     const size_t lds = (size_t)nqr * qb_stride * sizeof(float);
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((d->ndocs + 3) / 4, (size_t)c->num_cus * 8));
     const bool tiled = dim % 32 == 0 && dim <= 128 && !getenv("INNR_MAXSIM_GENERIC");
-    uint32_t* nq_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 4096);  // token counts of this pass
+    uint32_t* nq_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 16384);  // token counts, 4 per pass
     for (size_t p0 = 0; p0 < Tq_pad; p0 += kMsQ) {
         uint32_t nq_host[4] = {0, 0, 0, 0};
         for (int qi = 0; qi < nqr; ++qi) {
@@ -2105,7 +2326,7 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     if (engine != INNR_KNN_AUTO && engine != INNR_KNN_EXACT && engine != INNR_KNN_MFMA) return INNR_E_BAD_ARG;
     *out_k = 0;
     innr_ctx* c = d->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     if (dim != d->dim && Tq && d->T) {
         set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
         return INNR_E_DIM_MISMATCH;
@@ -2176,7 +2397,7 @@ innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks,
     if (engine != INNR_KNN_AUTO && engine != INNR_KNN_EXACT && engine != INNR_KNN_MFMA) return INNR_E_BAD_ARG;
     *out_k = 0;
     innr_ctx* c = d->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     if (dim != d->dim && Tq_stride && d->T) {
         set_error("dimension mismatch (doc): query dim %zu, document dim %zu", dim, d->dim);
         return INNR_E_DIM_MISMATCH;
@@ -2275,7 +2496,7 @@ innr_status innr_batch_dimension_variance(innr_batch* b, float* out) {
     if (!b || (!out && b->D)) return INNR_E_BAD_ARG;
     if (b->D == 0) return INNR_OK;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     if (b->dimvar.empty()) {
         INNR_TRY(c->misc.ensure(b->D * sizeof(float)));
         dimension_variance_kernel<<<(unsigned)((b->D + 63) / 64), 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N,
@@ -2304,13 +2525,64 @@ static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k,
     *out_k = 0;
     if (b->N == 0 || k == 0) return INNR_OK;  // batch.rs:624-629, 831-836
     const size_t kout = std::min(k, b->N);
-    if (kout > INNR_MAX_K) {
-        set_error("k=%zu exceeds INNR_MAX_K=%d", kout, INNR_MAX_K);
-        return INNR_E_UNSUPPORTED;
-    }
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
+    if (kout > INNR_MAX_K) {
+        // More results than a candidate list holds: the reference's own algorithm on the device -- every distance (in the
+        // caller's dimension order for batch_knn_reordered, batch.rs:640-648), a full sort of (distance, index) with the
+        // vectors that do not pass the predicate keyed last (batch.rs:839-849), truncate to min(k, passing).
+        const size_t N = b->N, ldq = round_up(D ? D : 1, 4);
+        if (N > 0x7fffffffull) {
+            set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 vectors per batch (N=%zu)", kout, N);
+            return INNR_E_UNSUPPORTED;
+        }
+        size_t tmp_bytes = 0, npass = N;
+        INNR_HIP_CHECK(full_sort_scratch_bytes(N, &tmp_bytes));
+        INNR_TRY(c->q_one.ensure(ldq * sizeof(float)));
+        INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
+        INNR_TRY(c->sort_keys.ensure(2 * N * sizeof(uint64_t)));
+        INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+        INNR_HIP_CHECK(hipMemsetAsync(c->q_one.p, 0, ldq * sizeof(float), c->stream));
+        if (D) INNR_HIP_CHECK(copy_in(c, c->q_one.p, q, D * sizeof(float)));
+        const uint8_t* dmask = nullptr;
+        if (mask) {
+            INNR_TRY(c->tmp_norms.ensure(b->ldN));
+            INNR_HIP_CHECK(hipMemsetAsync(c->tmp_norms.p, 0, b->ldN, c->stream));
+            INNR_HIP_CHECK(copy_in(c, c->tmp_norms.p, mask, N));
+            dmask = c->tmp_norms.as<uint8_t>();
+            npass = 0;
+            for (size_t i = 0; i < N; ++i) npass += mask[i] ? 1 : 0;
+        }
+        const size_t nchunks = b->ldN / kScanChunk;
+        const unsigned blocks = (unsigned)std::min<size_t>((nchunks + 3) / 4, (size_t)c->num_cus * 8);
+        if (order_host) {
+            INNR_TRY(c->misc.ensure(std::max<size_t>(D, 1) * sizeof(uint32_t)));
+            INNR_HIP_CHECK(copy_in(c, c->misc.p, order_host, D * sizeof(uint32_t)));
+            scan_scores_kernel<1, true, false, true><<<blocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, (uint32_t)D, c->q_one.as<float>(), ldq, nullptr, nullptr, c->scores.as<float>(), b->ldN,
+                c->misc.as<uint32_t>());
+        } else {
+            scan_scores_kernel<1, true, false><<<blocks, kScanThreads, 0, c->stream>>>(
+                b->V, b->ldN, (uint32_t)D, c->q_one.as<float>(), ldq, nullptr, nullptr, c->scores.as<float>(), b->ldN);
+        }
+        INNR_HIP_CHECK(hipGetLastError());
+        uint64_t* keys = c->sort_keys.as<uint64_t>();
+        INNR_HIP_CHECK(full_sort_scores(c->scores.as<float>(), N, true, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream, dmask));
+        const size_t n = std::min(kout, npass);
+        if (n) {
+            INNR_TRY(c->out_idx.ensure(n * sizeof(uint64_t)));
+            INNR_TRY(c->out_score.ensure(n * sizeof(float)));
+            emit_results_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(keys + N, 0, 1, (uint32_t)n, true, b->index_base,
+                                                                                c->out_idx.as<uint64_t>(), c->out_score.as<float>());
+            INNR_HIP_CHECK(hipGetLastError());
+            INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, n * sizeof(uint64_t)));
+            INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, n * sizeof(float)));
+        }
+        INNR_HIP_CHECK(ctx_sync(c));
+        *out_k = n;
+        return INNR_OK;
+    }
     INNR_TRY(c->q_row.ensure(std::max<size_t>(D, 1) * sizeof(float)));
     INNR_TRY(c->out_idx.ensure(kout * sizeof(uint64_t)));
     INNR_TRY(c->out_score.ensure(kout * sizeof(float)));
@@ -2380,7 +2652,7 @@ innr_status innr_batch_l2_squared_pruning(innr_batch* b, const float* q, size_t 
     *out_n = 0;
     if (b->N == 0) return INNR_OK;
     innr_ctx* c = b->ctx;
-    INNR_TRY(bind_device(c));
+    INNR_ENTER(c);
     // full exact distances on the device (bit-identical to batch_l2_squared) ...
     const size_t ldq = round_up(D ? D : 1, 4);
     INNR_TRY(c->q_row.ensure(ldq * sizeof(float)));
@@ -2426,12 +2698,311 @@ innr_status innr_merge_topk_dev(innr_ctx* ctx, int metric, const uint64_t* d_idx
         set_error("merge: kout=%zu > G*kin=%zu", kout, G * kin);
         return INNR_E_BAD_ARG;
     }
-    INNR_TRY(bind_device(ctx));
+    INNR_ENTER(ctx);
     merge_topk_kernel<<<(unsigned)Q, 64, 0, ctx->stream>>>(d_idx, d_score, (uint32_t)G, (uint32_t)Q, (uint32_t)kin,
                                                           (uint32_t)kout, metric == INNR_METRIC_L2SQ, d_out_idx,
                                                           d_out_score);
     INNR_HIP_CHECK(hipGetLastError());
     INNR_HIP_CHECK(ctx_sync(ctx));
+    return INNR_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// The exchange step of the sharded path: RCCL behind the boundary
+// =====================================================================================================================
+namespace innr {
+
+// librccl bound at run time: a process that never shards needs no RCCL, and a host that already carries one (PyTorch
+// bundles its own copy) must not get a second one mapped -- the copy already in the process is preferred.
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+static RcclApi* load_rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        if (const char* e = getenv("INNR_RCCL_LIB")) api.handle = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        for (int pass = 0; pass < 2 && !api.handle; ++pass)
+            for (const char* n : names) {
+                api.handle = dlopen(n, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_GLOBAL));
+                if (api.handle) break;
+            }
+        if (!api.handle) return;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+    });
+    if (!api.ok) {
+        set_error("RCCL is not available: %s", api.handle ? "librccl lacks a required symbol" : "librccl.so[.1] could not be loaded");
+        return nullptr;
+    }
+    return &api;
+}
+
+#define INNR_RCCL_CHECK(api, expr)                                                                 \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess) {                                                                   \
+            ::innr::set_error("%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__); \
+            return INNR_E_RCCL;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+// a shard's kNN result -> its exchange block (include/innr_hip.h): one thread per (query, slot)
+__global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* __restrict__ score, uint64_t index_base,
+                                 uint64_t shard_vectors, uint32_t Q, uint32_t kin, uint32_t k, uint64_t* __restrict__ block) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        block[0] = index_base;
+        block[1] = shard_vectors;
+    }
+    if (t >= (size_t)Q * k) return;
+    const uint32_t q = (uint32_t)(t / k), r = (uint32_t)(t % k);
+    uint64_t e = 0xFFFFFFFFull;  // no candidate
+    if (r < kin) {
+        const uint64_t g = idx[(size_t)q * kin + r];
+        const uint64_t local = g - index_base;
+        if (g >= index_base && local < 0xFFFFFFFFull)
+            e = ((uint64_t)__float_as_uint(score[(size_t)q * kin + r]) << 32) | local;
+    }
+    block[2 + t] = e;
+}
+
+// G gathered blocks -> best kout per query; one wave per query, rank counting on (preference, global index) like
+// merge_topk_kernel (kernels_topk.h)
+__global__ __launch_bounds__(64) void merge_blocks_kernel(const uint64_t* __restrict__ blocks, uint32_t G, uint32_t Q, uint32_t k,
+                                                          uint32_t kout, bool smaller_is_better, uint64_t* __restrict__ out_idx,
+                                                          float* __restrict__ out_score) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t total = G * k;
+    const size_t words = 2 + (size_t)Q * k;
+    const int lane = threadIdx.x;
+    for (uint32_t c = lane; c < total; c += 64) {
+        const uint32_t g = c / k, r = c % k;
+        const uint64_t* blk = blocks + (size_t)g * words;
+        const uint64_t e = blk[2 + (size_t)q * k + r];
+        const bool valid = (uint32_t)e != 0xFFFFFFFFu;
+        const uint64_t my_i = valid ? blk[0] + (uint32_t)e : ~0ull;
+        const float my_sf = __uint_as_float((uint32_t)(e >> 32));
+        const uint32_t my_p = !valid ? 0u : (smaller_is_better ? ~f32_ord(my_sf) : f32_ord(my_sf));
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < total; ++o) {
+            const uint32_t g2 = o / k, r2 = o % k;
+            const uint64_t* blk2 = blocks + (size_t)g2 * words;
+            const uint64_t e2 = blk2[2 + (size_t)q * k + r2];
+            const bool v2 = (uint32_t)e2 != 0xFFFFFFFFu;
+            const uint64_t i2 = v2 ? blk2[0] + (uint32_t)e2 : ~0ull;
+            const float sf = __uint_as_float((uint32_t)(e2 >> 32));
+            const uint32_t p = !v2 ? 0u : (smaller_is_better ? ~f32_ord(sf) : f32_ord(sf));
+            rank += (p > my_p || (p == my_p && (i2 < my_i || (i2 == my_i && o < c)))) ? 1u : 0u;
+        }
+        if (rank < kout) {
+            out_idx[(size_t)q * kout + rank] = my_i;
+            out_score[(size_t)q * kout + rank] = my_sf;
+        }
+    }
+}
+
+}  // namespace innr
+
+struct innr_comm {
+    innr_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    int rank = 0, world = 1;
+    DevBuf block, all, loc_idx, loc_sc, hdr;  // this rank's block, the gathered blocks, the local top-k
+};
+
+extern "C" {
+
+innr_status innr_comm_unique_id(void* id_out) {
+    if (!id_out) return INNR_E_BAD_ARG;
+    RcclApi* api = load_rccl();
+    if (!api) return INNR_E_RCCL;
+    static_assert(sizeof(ncclUniqueId) == INNR_COMM_ID_BYTES, "INNR_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+    ncclUniqueId id;
+    INNR_RCCL_CHECK(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return INNR_OK;
+}
+
+innr_status innr_comm_create(innr_ctx* ctx, const void* id, int rank, int world, innr_comm** out) {
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) {
+        set_error("innr_comm_create: bad ctx / id / rank %d of %d", rank, world);
+        return INNR_E_BAD_ARG;
+    }
+    RcclApi* api = load_rccl();
+    if (!api) return INNR_E_RCCL;
+    INNR_ENTER(ctx);
+    innr_comm* cm = new (std::nothrow) innr_comm();
+    if (!cm) return INNR_E_OOM;
+    cm->ctx = ctx;
+    cm->rank = rank;
+    cm->world = world;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t r = api->CommInitRank(&cm->comm, world, uid, rank);  // collective: returns once every rank has joined
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api->GetErrorString(r));
+        delete cm;
+        return INNR_E_RCCL;
+    }
+    cm->owned = true;
+    *out = cm;
+    return INNR_OK;
+}
+
+innr_status innr_comm_attach(innr_ctx* ctx, void* nccl_comm, int rank, int world, innr_comm** out) {
+    if (!ctx || !nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return INNR_E_BAD_ARG;
+    if (!load_rccl()) return INNR_E_RCCL;
+    innr_comm* cm = new (std::nothrow) innr_comm();
+    if (!cm) return INNR_E_OOM;
+    cm->ctx = ctx;
+    cm->comm = static_cast<ncclComm_t>(nccl_comm);
+    cm->rank = rank;
+    cm->world = world;
+    *out = cm;
+    return INNR_OK;
+}
+
+void innr_comm_destroy(innr_comm* cm) {
+    if (!cm) return;
+    {
+        CtxGuard guard(cm->ctx);
+        if (cm->ctx) {
+            (void)hipSetDevice(cm->ctx->device);
+            (void)ctx_sync(cm->ctx);
+        }
+        if (cm->owned && cm->comm) {
+            RcclApi* api = load_rccl();
+            if (api) (void)api->CommDestroy(cm->comm);
+        }
+        DevBuf* bufs[] = {&cm->block, &cm->all, &cm->loc_idx, &cm->loc_sc, &cm->hdr};
+        for (DevBuf* b : bufs) b->release();
+    }
+    delete cm;
+}
+
+int innr_comm_rank(const innr_comm* cm) { return cm ? cm->rank : -1; }
+int innr_comm_world(const innr_comm* cm) { return cm ? cm->world : 0; }
+
+size_t innr_topk_block_words(size_t Q, size_t k) { return 2 + Q * k; }
+
+innr_status innr_topk_pack_dev(innr_ctx* ctx, const uint64_t* d_idx, const float* d_score, uint64_t index_base,
+                               uint64_t shard_vectors, size_t Q, size_t kin, size_t k, uint64_t* d_block) {
+    if (!ctx || !d_block || kin > k || (Q * kin && (!d_idx || !d_score)) || Q * k >= 0xFFFFFFFFull) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
+    const size_t n = std::max<size_t>(Q * k, 1);
+    pack_topk_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_idx, d_score, index_base, shard_vectors, (uint32_t)Q,
+                                                                         (uint32_t)kin, (uint32_t)k, d_block);
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+innr_status innr_allgather_topk_dev(innr_comm* cm, const uint64_t* d_block, size_t Q, size_t k, uint64_t* d_all_blocks) {
+    if (!cm || !cm->comm || !d_block || !d_all_blocks) return INNR_E_BAD_ARG;
+    RcclApi* api = load_rccl();
+    if (!api) return INNR_E_RCCL;
+    INNR_ENTER(cm->ctx);
+    const size_t bytes = innr_topk_block_words(Q, k) * sizeof(uint64_t);
+    INNR_RCCL_CHECK(api, api->AllGather(d_block, d_all_blocks, bytes, ncclUint8, cm->comm, cm->ctx->stream));
+    return INNR_OK;
+}
+
+innr_status innr_merge_blocks_dev(innr_ctx* ctx, int metric, const uint64_t* d_all_blocks, size_t G, size_t Q, size_t k,
+                                  uint64_t* d_out_idx, float* d_out_score, size_t* out_k) {
+    if (!ctx || !out_k || !metric_ok(metric) || G == 0 || !d_all_blocks) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    if (Q == 0 || k == 0) return INNR_OK;
+    if (G * k >= 0xFFFFFFFFull || Q >= 0xFFFFFFFFull) return INNR_E_UNSUPPORTED;
+    INNR_ENTER(ctx);
+    // k' = min(k, vectors in all shards): the shard sizes travel in the blocks' headers
+    const size_t words = innr_topk_block_words(Q, k);
+    std::vector<uint64_t> hdr(2 * G);
+    INNR_HIP_CHECK(hipMemcpy2DAsync(hdr.data(), 16, d_all_blocks, words * sizeof(uint64_t), 16, G, hipMemcpyDeviceToHost, ctx->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0;
+    for (size_t g = 0; g < G; ++g) total += hdr[2 * g + 1];
+    const size_t kout = (size_t)std::min<uint64_t>(k, total);
+    if (kout == 0) return INNR_OK;
+    if (!d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
+    merge_blocks_kernel<<<(unsigned)Q, 64, 0, ctx->stream>>>(d_all_blocks, (uint32_t)G, (uint32_t)Q, (uint32_t)k, (uint32_t)kout,
+                                                            metric == INNR_METRIC_L2SQ, d_out_idx, d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(ctx_sync(ctx));
+    *out_k = kout;
+    return INNR_OK;
+}
+
+innr_status innr_sharded_knn_dev(innr_comm* cm, innr_batch* shard, int metric, const float* d_queries, size_t Q, size_t D,
+                                 size_t k, int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
+                                 innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!cm || !shard || !out_k || shard->ctx != cm->ctx) {
+        set_error("innr_sharded_knn_dev: null comm / shard, or the shard lives on another context");
+        return INNR_E_BAD_ARG;
+    }
+    *out_k = 0;
+    if (Q == 0 || k == 0) return INNR_OK;  // nothing to exchange (every rank takes this branch: same arguments)
+    if (k > ((size_t)1 << 20)) {
+        set_error("innr_sharded_knn_dev: k=%zu: at most 2^20 candidates per shard and query are exchanged", k);
+        return INNR_E_UNSUPPORTED;
+    }
+    innr_ctx* c = cm->ctx;
+    INNR_ENTER(c);
+    const size_t words = innr_topk_block_words(Q, k);
+    INNR_TRY(cm->loc_idx.ensure(Q * k * sizeof(uint64_t)));
+    INNR_TRY(cm->loc_sc.ensure(Q * k * sizeof(float)));
+    INNR_TRY(cm->block.ensure(words * sizeof(uint64_t)));
+    INNR_TRY(cm->all.ensure((size_t)cm->world * words * sizeof(uint64_t)));
+    size_t kin = 0;
+    const bool u8 = shard->C8 != nullptr && shard->V == nullptr;
+    // the local search; a dimension mismatch is reported before anything is exchanged (it is the same on every rank)
+    if (u8)
+        INNR_TRY(innr_batch_knn_u8_dev(shard, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin, stats));
+    else
+        INNR_TRY(innr_batch_knn_dev(shard, metric, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin,
+                                    stats));
+    INNR_TRY(innr_topk_pack_dev(c, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), shard->index_base, shard->N, Q, kin, k,
+                                cm->block.as<uint64_t>()));
+    INNR_TRY(innr_allgather_topk_dev(cm, cm->block.as<uint64_t>(), Q, k, cm->all.as<uint64_t>()));
+    return innr_merge_blocks_dev(c, u8 ? INNR_METRIC_DOT : metric, cm->all.as<uint64_t>(), (size_t)cm->world, Q, k, d_out_idx,
+                                 d_out_score, out_k);
+}
+
+innr_status innr_sharded_knn(innr_comm* cm, innr_batch* shard, int metric, const float* queries, size_t Q, size_t D, size_t k,
+                             int engine, uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!cm || !shard || !out_k || shard->ctx != cm->ctx) return INNR_E_BAD_ARG;
+    *out_k = 0;
+    if (Q == 0 || k == 0) return INNR_OK;
+    if ((!queries && D) || !out_idx || !out_score) return INNR_E_BAD_ARG;
+    innr_ctx* c = cm->ctx;
+    INNR_ENTER(c);
+    INNR_TRY(c->q_row.ensure(std::max<size_t>(Q * D, 1) * sizeof(float)));
+    INNR_TRY(c->out_idx.ensure(Q * k * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(Q * k * sizeof(float)));
+    if (D) INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
+    INNR_TRY(innr_sharded_knn_dev(cm, shard, metric, c->q_row.as<float>(), Q, D, k, engine, c->out_idx.as<uint64_t>(),
+                                  c->out_score.as<float>(), out_k, stats));
+    if (*out_k) {
+        INNR_HIP_CHECK(copy_out(c, out_idx, c->out_idx.p, Q * *out_k * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * *out_k * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
+    }
     return INNR_OK;
 }
 

@@ -557,6 +557,46 @@ __global__ void rerank_prepare_kernel(const uint64_t* __restrict__ cand, uint32_
     sel[t] = v;
 }
 
+// Re-rank with more candidates per query than a candidate list holds (innr_batch_rerank*, kc > 256): one thread per
+// (query, candidate) computes the exact score in the reference's order and writes its composite; the caller sorts every
+// query's kc composites. Out-of-range indices are clamped into the batch and flagged, as in rerank_prepare_kernel.
+template <int MET>
+__global__ __launch_bounds__(256) void rerank_scores_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
+                                                             const float* __restrict__ Qm, const float* __restrict__ norms,
+                                                             const float* __restrict__ qnorm, const uint64_t* __restrict__ cand,
+                                                             uint32_t Q, uint32_t kc, uint64_t index_base,
+                                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ bad) {
+    constexpr bool COS = MET == 1, L2 = MET == 2;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Q * kc) return;
+    const uint32_t q = (uint32_t)(t / kc);
+    const uint64_t g = cand[t];
+    uint64_t i64 = g - index_base;
+    if (g < index_base || i64 >= N) {
+        atomicOr(bad, 1u);
+        i64 = 0;
+    }
+    const uint32_t i = (uint32_t)i64;
+    const float* qv = Qm + (size_t)q * D;
+    const float* col = V + i;
+    float acc = 0.0f;
+    if (L2) {
+#pragma unroll 8
+        for (uint32_t d = 0; d < D; ++d) {
+            const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
+            acc = ex::mad2(acc, diff, diff);
+        }
+    } else {
+#pragma unroll 8
+        for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
+    }
+    if (COS) {
+        const float qn = qnorm[q], vn = norms[i];
+        acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
+    }
+    keys[t] = cand_make(score_pref<L2>(acc), i);
+}
+
 // Threshold seeding. Without it every slice appends its whole first tile (no list has a threshold yet, the chip-wide
 // bound is still 0): 128 x 128 slices = 16 384 appends per query, 94 % of all appends of a C2 launch and ~4 % of its
 // time. The exact engine first finds the KP best of a corpus PREFIX per query; their KP-th exact score, lowered by

@@ -58,12 +58,14 @@ __device__ __forceinline__ float cosine_epilogue(float dot, float qn, float vn) 
 }
 
 // ---- materialising variant: out[j*ldo + i] for all i (innr_batch_scores) -----------------------------
-template <int QB, bool L2, bool COS>
+// ORD: dimensions walked in `order` (batch_knn_reordered beyond the candidate lists: all scores, then a full sort)
+template <int QB, bool L2, bool COS, bool ORD = false>
 __global__ __launch_bounds__(kScanThreads) void scan_scores_kernel(const float* __restrict__ V, size_t ldN,
                                                                     uint32_t D, const float* __restrict__ Qm,
                                                                     size_t ldq, const float* __restrict__ norms,
                                                                     const float* __restrict__ qnorm,
-                                                                    float* __restrict__ out, size_t ldo) {
+                                                                    float* __restrict__ out, size_t ldo,
+                                                                    const uint32_t* __restrict__ order = nullptr) {
     const size_t nchunks = ldN / kScanChunk;
     const size_t wave = ((size_t)blockIdx.x * kScanThreads + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * kScanThreads) >> 6;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_scores_kernel(const float* 
     for (size_t ch = wave; ch < nchunks; ch += nwaves) {
         const size_t col = ch * kScanChunk + (size_t)lane * 4;
         float acc[QB][4];
-        scan_accumulate<QB, L2>(V, ldN, D, col, Qm, ldq, acc);
+        scan_accumulate<QB, L2, ORD>(V, ldN, D, col, Qm, ldq, acc, order);
         float4 vn = make_float4(0, 0, 0, 0);
         if (COS) vn = *reinterpret_cast<const float4*>(norms + col);
 #pragma unroll

@@ -15,6 +15,8 @@ pub mod ffi {
     #[repr(C)]
     pub struct InnrDocs { _p: [u8; 0] }
     #[repr(C)]
+    pub struct InnrComm { _p: [u8; 0] } // ctx + RCCL communicator (the exchange step of the sharded path)
+    #[repr(C)]
     #[derive(Default, Clone, Copy, Debug)]
     pub struct InnrKnnStats {
         pub engine: c_int,
@@ -25,6 +27,8 @@ pub mod ffi {
     }
     pub const INNR_OK: c_int = 0;
     pub const INNR_E_DIM_MISMATCH: c_int = -1;
+    pub const INNR_E_RCCL: c_int = -5;
+    pub const INNR_COMM_ID_BYTES: usize = 128;
     pub const INNR_METRIC_DOT: c_int = 0;
     pub const INNR_METRIC_L2SQ: c_int = 1;
     pub const INNR_METRIC_COSINE: c_int = 2;
@@ -33,54 +37,72 @@ pub mod ffi {
     pub const INNR_KNN_MFMA: c_int = 2;
     pub const INNR_KNN_MFMA_BF16: c_int = 3; // bf16 filter + exact f32 re-score and proof: same results (dot, k <= 48)
     extern "C" {
+        // ---- generated from include/innr_hip.h by tools/gen_rust_ffi.py: begin
         pub fn innr_ctx_create(device: c_int, out: *mut *mut InnrCtx) -> c_int;
         pub fn innr_ctx_destroy(ctx: *mut InnrCtx);
         pub fn innr_ctx_set_stream(ctx: *mut InnrCtx, hip_stream: *mut c_void) -> c_int;
         pub fn innr_ctx_synchronize(ctx: *mut InnrCtx) -> c_int;
         pub fn innr_last_error() -> *const c_char;
+        pub fn innr_version() -> *const c_char;
         pub fn innr_batch_upload_colmajor(ctx: *mut InnrCtx, data: *const f32, n: usize, d: usize, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_upload_rowmajor(ctx: *mut InnrCtx, rows: *const f32, n: usize, d: usize, out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_batch_generate(ctx: *mut InnrCtx, n: usize, d: usize, generator: c_int, seed: u64, row0: u64, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_free(b: *mut InnrBatch);
+        pub fn innr_batch_auto_engine(b: *const InnrBatch, q: usize) -> c_int;
+        pub fn innr_batch_num_vectors(b: *const InnrBatch) -> usize;
+        pub fn innr_batch_dimension(b: *const InnrBatch) -> usize;
         pub fn innr_batch_download_colmajor(b: *mut InnrBatch, out: *mut f32) -> c_int;
         pub fn innr_batch_set_index_base(b: *mut InnrBatch, base: u64) -> c_int;
         pub fn innr_batch_scores(b: *mut InnrBatch, metric: c_int, q: *const f32, d: usize, norms: *const f32, out: *mut f32) -> c_int;
         pub fn innr_batch_norms(b: *mut InnrBatch, out: *mut f32) -> c_int;
-        pub fn innr_batch_knn(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int,
-                              out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
-        // L2 variants (batch.rs:320-365, 572-659, 820-882)
-        pub fn innr_batch_dimension_variance(b: *mut InnrBatch, out: *mut f32) -> c_int;
-        pub fn innr_batch_knn_filtered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize, mask: *const u8,
-                                       out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
-        pub fn innr_batch_knn_reordered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize,
-                                        out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
-        pub fn innr_batch_l2_squared_pruning(b: *mut InnrBatch, q: *const f32, d: usize, threshold: f32,
-                                             out_idx: *mut u64, out_dist: *mut f32, cap: usize, out_n: *mut usize) -> c_int;
-        // scalar.rs
-        pub fn innr_batch_upload_u8(ctx: *mut InnrCtx, codes: *const u8, n: usize, d: usize, alpha: f32, offset: f32,
-                                    out: *mut *mut InnrBatch) -> c_int;
-        pub fn innr_batch_knn_u8(b: *mut InnrBatch, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int,
-                                 out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_batch_knn(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_batch_knn_dev(b: *mut InnrBatch, metric: c_int, d_queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_batch_upload_u8(ctx: *mut InnrCtx, codes: *const u8, n: usize, d: usize, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_batch_generate_u8(ctx: *mut InnrCtx, n: usize, d: usize, seed: u64, row0: u64, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_batch_download_u8(b: *mut InnrBatch, out: *mut u8) -> c_int;
+        pub fn innr_batch_scores_u8(b: *mut InnrBatch, q: *const f32, d: usize, out: *mut f32) -> c_int;
+        pub fn innr_batch_knn_u8(b: *mut InnrBatch, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_batch_knn_u8_dev(b: *mut InnrBatch, d_queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
         pub fn innr_quantize_u8(values: *const f32, n: usize, alpha: f32, offset: f32, out: *mut u8);
         pub fn innr_mixed_dot_u8_f32(a: *const f32, b: *const u8, n: usize) -> f32;
-        // maxsim.rs
-        pub fn innr_maxsim_pair(q: *const f32, nq: usize, d: *const f32, nd: usize, dim: usize, cosine: c_int, out: *mut f32) -> c_int;
-        pub fn innr_maxsim_upload(ctx: *mut InnrCtx, tokens: *const f32, doc_len: *const u32, docs: usize, t: usize, dim: usize,
-                                  out: *mut *mut InnrDocs) -> c_int;
+        pub fn innr_batch_quantize_u8(f32_batch: *mut InnrBatch, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_batch_minmax(f32_batch: *mut InnrBatch, out_min: *mut f32, out_max: *mut f32, out_any: *mut c_int) -> c_int;
+        pub fn innr_maxsim_upload(ctx: *mut InnrCtx, tokens: *const f32, doc_len: *const u32, docs: usize, t: usize, dim: usize, out: *mut *mut InnrDocs) -> c_int;
+        pub fn innr_maxsim_generate(ctx: *mut InnrCtx, docs: usize, t: usize, dim: usize, seed: u64, row0: u64, out: *mut *mut InnrDocs) -> c_int;
         pub fn innr_docs_free(d: *mut InnrDocs);
+        pub fn innr_docs_count(d: *const InnrDocs) -> usize;
+        pub fn innr_docs_set_index_base(d: *mut InnrDocs, base: u64) -> c_int;
         pub fn innr_maxsim_scores(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, out: *mut f32) -> c_int;
-        pub fn innr_maxsim_topk(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int,
-                                out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
-        // two-stage pipelines: exact re-rank of given candidates; matryoshka prefix view (dense.rs:436-462)
-        pub fn innr_batch_rerank(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, cand: *const u64, kc: usize,
-                                 k: usize, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
-        pub fn innr_batch_prefix_view(parent: *mut InnrBatch, prefix_dims: usize, out: *mut *mut InnrBatch) -> c_int;
-        // distance.rs / dense.rs portable pairwise functions (host)
+        pub fn innr_maxsim_topk(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int, out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_maxsim_topk_multi(d: *mut InnrDocs, cosine: c_int, qtoks: *const f32, q: usize, tq: *const u32, tq_stride: usize, dim: usize, k: usize, engine: c_int, out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_batch_dimension_variance(b: *mut InnrBatch, out: *mut f32) -> c_int;
+        pub fn innr_batch_knn_filtered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize, mask: *const u8, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_knn_reordered(b: *mut InnrBatch, q: *const f32, d: usize, k: usize, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_l2_squared_pruning(b: *mut InnrBatch, q: *const f32, d: usize, threshold: f32, out_idx: *mut u64, out_dist: *mut f32, cap: usize, out_n: *mut usize) -> c_int;
         pub fn innr_dot_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_cosine_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_l2sq_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_l1_f32(a: *const f32, b: *const f32, n: usize) -> f32;
         pub fn innr_hamming_u8(a: *const u8, b: *const u8, n: usize) -> u32;
         pub fn innr_slot_distance_u32(a: *const u32, b: *const u32, n: usize) -> f32;
+        pub fn innr_maxsim_pair(q: *const f32, nq: usize, d: *const f32, nd: usize, dim: usize, cosine: c_int, out: *mut f32) -> c_int;
+        pub fn innr_batch_rerank(b: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, cand: *const u64, kc: usize, k: usize, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_rerank_dev(b: *mut InnrBatch, metric: c_int, d_queries: *const f32, q: usize, d: usize, d_cand: *const u64, kc: usize, k: usize, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_batch_prefix_view(parent: *mut InnrBatch, prefix_dims: usize, out: *mut *mut InnrBatch) -> c_int;
+        pub fn innr_merge_topk_dev(ctx: *mut InnrCtx, metric: c_int, d_idx: *const u64, d_score: *const f32, g: usize, q: usize, kin: usize, kout: usize, d_out_idx: *mut u64, d_out_score: *mut f32) -> c_int;
+        pub fn innr_comm_unique_id(id_out: *mut c_void) -> c_int;
+        pub fn innr_comm_create(ctx: *mut InnrCtx, id: *const c_void, rank: c_int, world: c_int, out: *mut *mut InnrComm) -> c_int;
+        pub fn innr_comm_attach(ctx: *mut InnrCtx, nccl_comm: *mut c_void, rank: c_int, world: c_int, out: *mut *mut InnrComm) -> c_int;
+        pub fn innr_comm_destroy(comm: *mut InnrComm);
+        pub fn innr_comm_rank(comm: *const InnrComm) -> c_int;
+        pub fn innr_comm_world(comm: *const InnrComm) -> c_int;
+        pub fn innr_topk_block_words(q: usize, k: usize) -> usize;
+        pub fn innr_topk_pack_dev(ctx: *mut InnrCtx, d_idx: *const u64, d_score: *const f32, index_base: u64, shard_vectors: u64, q: usize, kin: usize, k: usize, d_block: *mut u64) -> c_int;
+        pub fn innr_allgather_topk_dev(comm: *mut InnrComm, d_block: *const u64, q: usize, k: usize, d_all_blocks: *mut u64) -> c_int;
+        pub fn innr_merge_blocks_dev(ctx: *mut InnrCtx, metric: c_int, d_all_blocks: *const u64, g: usize, q: usize, k: usize, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize) -> c_int;
+        pub fn innr_sharded_knn_dev(comm: *mut InnrComm, shard: *mut InnrBatch, metric: c_int, d_queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_sharded_knn(comm: *mut InnrComm, shard: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        // ---- generated: end
     }
 }
 
@@ -88,6 +110,10 @@ use std::ffi::CStr;
 use std::sync::OnceLock;
 
 struct Ctx(*mut ffi::InnrCtx);
+// The library serialises the entry points of one context itself: every extern "C" function holds the context's
+// (recursive) mutex for its whole duration (CtxGuard, innr_amd/csrc/api.hip), so concurrent calls from several host
+// threads on this process-wide context -- and on the batches created on it -- are safe; they run one at a time.
+// Threads that should overlap their GPU work create one context each (innr_ctx_create is cheap).
 unsafe impl Send for Ctx {}
 unsafe impl Sync for Ctx {}
 
@@ -181,6 +207,9 @@ pub mod batch {
             (0..self.dimension).map(|d| self.get(d, vec_idx)).collect()
         }
         pub(crate) fn handle(&self) -> *mut ffi::InnrBatch { self.h }
+        /// range-partitioned corpus (sharded::Comm): this batch holds rows [base, base + num_vectors) of the global
+        /// corpus; every index it reports is `base + local index`
+        pub fn set_index_base(&self, base: u64) { check(unsafe { ffi::innr_batch_set_index_base(self.h, base) }) }
     }
 
     fn scores_into(metric: i32, query: &[f32], batch: &VerticalBatch, norms: Option<&[f32]>, out: &mut Vec<f32>) {
@@ -466,5 +495,56 @@ pub mod distance {
     }
     impl Distance<u32> for DistSlotU32 {                                                                                         // :128-143
         fn eval(&self, a: &[u32], b: &[u32]) -> f32 { assert_eq!(a.len(), b.len()); unsafe { ffi::innr_slot_distance_u32(a.as_ptr(), b.as_ptr(), a.len()) } }
+    }
+}
+
+/// The sharded path (no counterpart in the reference, which is one process: BASELINE north_star "range-partitioned
+/// across the 8 GPUs of one node with a final RCCL all-gather of per-shard top-k candidates"). One process per GPU; the
+/// host program ships `unique_id()` from rank 0 to the other ranks by its own means (MPI, a file, a socket) and every
+/// rank calls `Comm::create`. `knn_*` is then ONE library call per query batch: local search on this rank's shard
+/// (rows [base, base + n) of the global corpus, `VerticalBatch::set_index_base(base)`), one `ncclAllGather` of
+/// 8-byte candidates and the merge, all on the context's stream; every rank receives the same global top-k.
+pub mod sharded {
+    use super::*;
+
+    pub struct Comm { h: *mut ffi::InnrComm }
+    unsafe impl Send for Comm {}
+    impl Drop for Comm {
+        fn drop(&mut self) { unsafe { ffi::innr_comm_destroy(self.h) } }
+    }
+
+    /// rank 0 only (ncclGetUniqueId)
+    #[must_use] pub fn unique_id() -> [u8; ffi::INNR_COMM_ID_BYTES] {
+        let mut id = [0u8; ffi::INNR_COMM_ID_BYTES];
+        check(unsafe { ffi::innr_comm_unique_id(id.as_mut_ptr().cast()) });
+        id
+    }
+
+    impl Comm {
+        /// collective over all `world` ranks (ncclCommInitRank on this process's GPU)
+        pub fn create(id: &[u8; ffi::INNR_COMM_ID_BYTES], rank: usize, world: usize) -> Self {
+            let mut h = std::ptr::null_mut();
+            check(unsafe { ffi::innr_comm_create(ctx(), id.as_ptr().cast(), rank as i32, world as i32, &mut h) });
+            Comm { h }
+        }
+        #[must_use] pub fn rank(&self) -> usize { unsafe { ffi::innr_comm_rank(self.h) as usize } }
+        #[must_use] pub fn world(&self) -> usize { unsafe { ffi::innr_comm_world(self.h) as usize } }
+
+        /// global top-k of `queries` (row-major, `dim` each) over every rank's shard -- `batch_knn_dot` / `_cosine` /
+        /// `batch_knn` of the whole corpus (batch.rs:742-764, 777-800, 385-411), identical on every rank. Collective.
+        pub fn knn(&self, shard: &batch::VerticalBatch, metric: i32, queries: &[f32], k: usize) -> Vec<Vec<(usize, f32)>> {
+            let dim = shard.dimension();
+            assert!(dim > 0 && queries.len() % dim == 0);
+            let nq = queries.len() / dim;
+            let mut idx = vec![0u64; nq * k.max(1)];
+            let mut sc = vec![0f32; nq * k.max(1)];
+            let mut got = 0usize;
+            let mut st = ffi::InnrKnnStats::default();
+            check(unsafe {
+                ffi::innr_sharded_knn(self.h, shard.handle(), metric, queries.as_ptr(), nq, dim, k, ffi::INNR_KNN_AUTO,
+                                      idx.as_mut_ptr(), sc.as_mut_ptr(), &mut got, &mut st)
+            });
+            (0..nq).map(|q| (0..got).map(|r| (idx[q * got + r] as usize, sc[q * got + r])).collect()).collect()
+        }
     }
 }

@@ -67,6 +67,72 @@ def test_fails_loudly_without_gpu(built):
     assert "no CPU fallback" in built.last_error() or "HIP" in built.last_error() or "device" in built.last_error()
 
 
+def test_gemm_asm_guard(built):
+    """The GEMM kernels wait for their inline-asm loads with hand-counted s_waitcnt; whether the register allocator kept
+    the operand registers untouched in between, and whether every asm load takes its base from an in-statement
+    s_mov_b64, is checked on the ISA of every instantiation (tools/check_gemm_asm.py) -- here, on the CPU box, before any
+    GPU time is spent. `make asm` regenerates the ISA only when a kernel source changed."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("build-box check (the ISA listing is not shipped to the GPU box)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "innr_amd", "csrc"), "asm"])
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_gemm_asm.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "FAIL" not in r.stdout and r.stdout.count(" ok") >= 40, r.stdout
+
+
+RUST_SHIM = os.path.join(ROOT, "rust", "innr-hip", "src", "lib.rs")
+
+
+def _c_params(decl: str):
+    """parameter C types of one prototype, normalised: pointers -> 'ptr', everything else its base type"""
+    args = decl[decl.index("(") + 1:decl.rindex(")")].strip()
+    if args in ("", "void"):
+        return []
+    out = []
+    for a in args.split(","):
+        a = a.strip()
+        if "*" in a:
+            out.append("ptr")
+        else:
+            out.append(re.sub(r"\s+\w+$", "", a).strip())  # drop the parameter name
+    return out
+
+
+def _rust_params(decl: str):
+    args = decl[decl.index("(") + 1:decl.rindex(")")].strip()
+    if not args:
+        return []
+    out = []
+    for a in args.split(","):
+        a = a.strip()
+        if not a:
+            continue
+        ty = a.split(":", 1)[1].strip()
+        out.append("ptr" if ty.startswith("*") else ty)
+    return out
+
+
+C_TO_RUST = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32", "innr_status": "c_int"}
+
+
+def test_rust_shim_binds_the_whole_header():
+    """rust/innr-hip `mod ffi` against include/innr_hip.h, as text (this image has no rustc): every declared entry point is
+    bound, nothing else is, and each binding has the header's parameter count with pointer / scalar kinds and scalar
+    types matching."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    protos = {m.group(2): m.group(0) for m in re.finditer(r"([\w\s\*]+?)\b(innr_[a-z0-9_]+)\s*\([^;{]*\)\s*;", hdr)}
+    rs = open(RUST_SHIM).read()
+    ffi = rs[rs.index("mod ffi"):]
+    ffi = ffi[:ffi.index("\n}\n") + 3]
+    ffi = re.sub(r"//.*", "", ffi)
+    bound = {m.group(1): m.group(0) for m in re.finditer(r"pub fn (innr_[a-z0-9_]+)\s*\([^;]*\)[^;]*;", ffi)}
+    assert sorted(bound) == sorted(protos), (sorted(set(protos) - set(bound)), sorted(set(bound) - set(protos)))
+    for name, decl in protos.items():
+        want = [t if t == "ptr" else C_TO_RUST.get(t, t) for t in _c_params(decl)]
+        got = _rust_params(bound[name])
+        assert got == want, (name, got, want)
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "innr_amd")):
         for f in files:

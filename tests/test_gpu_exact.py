@@ -204,12 +204,36 @@ def test_knn_exact_uniform_data(B, innr, metric):
     _check_knn(B, innr, metric, rows, data, _queries(24, 96, 8, uniform=True), 20, innr.KNN_EXACT)
 
 
-def test_knn_k_limit_is_loud_where_it_remains(B, innr):
-    # batch_knn / _dot / _cosine take any k (full-sort path beyond INNR_MAX_K); the L2 variants keep the limit and say so
-    vb = B.VerticalBatch.generate(1000, 8, 0)
-    assert len(B.batch_knn_dot(np.zeros(8, np.float32), vb, 241).indices) == 241
-    with pytest.raises(innr.InnrError):
-        B.batch_knn_filtered(np.zeros(8, np.float32), vb, 241, lambda i: True)
+def test_no_k_limit_anywhere(B, innr):
+    # every kNN entry point takes any k <= N, like the reference (batch.rs:395, 621-659, 820-882): beyond INNR_MAX_K the
+    # candidate-list engines hand over to "all scores + device sort"; INNR_E_UNSUPPORTED is not reachable through k
+    n, dim = 3000, 24
+    rows, data = _corpus(n, dim, 4, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    q = _queries(1, dim, 12, uniform=True)[0]
+    assert len(B.batch_knn_dot(np.zeros(dim, np.float32), vb, 241).indices) == 241
+    for k in (241, 1000, n, n + 5):
+        r = B.batch_knn_reordered(q, vb, k)
+        oi, os_ = oracle.batch_knn_reordered(q, data, k)
+        assert r.indices == oi.tolist() and bits_equal(np.float32(r.scores), os_), k
+        pred = lambda i: i % 3 != 1  # noqa: E731
+        mask = np.array([1 if pred(i) else 0 for i in range(n)], dtype=np.uint8)
+        r = B.batch_knn_filtered(q, vb, k, pred)
+        oi, os_ = oracle.batch_knn_filtered(q, data, k, mask)
+        assert r.indices == oi.tolist() and bits_equal(np.float32(r.scores), os_), k
+    # fewer vectors pass than k (> INNR_MAX_K): k = min(k, passing), batch.rs:849
+    r = B.batch_knn_filtered(q, vb, 500, lambda i: i < 300)
+    oi, os_ = oracle.batch_knn_filtered(q, data, 500, (np.arange(n) < 300).astype(np.uint8))
+    assert len(r.indices) == 300 and r.indices == oi.tolist() and bits_equal(np.float32(r.scores), os_)
+
+
+@pytest.mark.parametrize("nq", [2, 3, 5, 6, 7, 9, 11])
+def test_knn_exact_ragged_query_tails(B, innr, nq):
+    # 2-3 queries share ONE 4-query corpus pass, 5-7 one 8-query pass (zero rows as padding): results per query unchanged
+    rows, data = _corpus(9000, 40, 23, uniform=True)
+    vb = None
+    for metric in ("dot", "cos", "l2"):
+        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(nq, 40, 99, uniform=True), 7, innr.KNN_EXACT)
 
 
 def test_knn_ties_resolve_to_lower_index(B, innr):

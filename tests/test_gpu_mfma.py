@@ -261,6 +261,79 @@ def test_knn_mfma_near_ties_around_the_cut(B, innr, cluster):
             assert st.queries_fallback <= 2, st.queries_fallback
 
 
+def test_knn_mfma_minority_of_unproven_queries_retries_with_longer_lists(B, innr):
+    """20 of 96 queries get a cluster of 100 near-identical top vectors: more than the 32 candidates the first pass keeps
+    (proof fails), fewer than 256 -- the engine re-runs those 20 as one batch with 256-entry lists instead of an exact
+    corpus scan per group. Results identical to the oracle either way; the other 76 queries stay proven."""
+    n, dim, k = 80_000, 64, 10
+    rows = oracle.generate_uniform(n, dim, 41) * np.float32(0.25)
+    qs = oracle.generate_uniform(96, dim, 42)
+    rng = np.random.default_rng(9)
+    for j in range(0, 96, 5):
+        pos = rng.choice(n, size=100, replace=False)
+        noise = (1.0 + rng.integers(-3, 4, size=(100, dim)) * 2.0 ** -23).astype(np.float32)
+        rows[pos] = (qs[j] * np.float32(1.5)) * noise
+    data = oracle.from_rows(rows)
+    vb = B.VerticalBatch.from_rows(rows)
+    for metric in ("dot", "cos"):
+        fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi}[metric]
+        ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine}[metric]
+        st = innr.KnnStats()
+        idx, sc = fn(qs, vb, k, engine=innr.KNN_MFMA, stats=st)
+        for j, q in enumerate(qs):
+            oi, os_ = ofn(q, data, k)
+            assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j)
+        assert 16 <= st.queries_fallback <= 24, st.queries_fallback
+
+
+def test_config5_cosine_4096_queries_two_logical_shards(B, innr):
+    """BASELINE.json configs[4] per-GPU workload: batch_knn_cosine f32, a 10M x 768 shard, a 4096-query batch, k = 10 --
+    and the exchange contract on G = 2 logical shards of 10M rows each (index bases 0 and 10M): per-shard top-k through
+    the sharded path's device-resident local search (innr_batch_knn_dev), merge by innr_merge_topk_dev.
+    Size-independent checks: self-match (query j IS corpus row picks[j], somewhere in the 20M rows -> global top-1 with
+    cosine ~ 1), sortedness, uniqueness, range; the GEMM engine against the bit-exact engine on a query subset of each
+    shard; the device merge against a numpy (score desc, index asc) merge of the two shard results for all 4096 queries."""
+    import torch
+    from innr_amd.dist import _gpu_local_search, _gpu_merge
+    n, dim, nq, k, g = 10_000_000, 768, 4096, 10, 2
+    ctx = innr.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    picks = (np.arange(nq, dtype=np.int64) * 4_877 + 321) % (g * n)
+    qs = np.concatenate([oracle.generate_uniform(1, dim, 0, row0=int(r)) for r in picks])
+    q_dev = torch.from_numpy(qs).to(dev)
+    all_i = torch.empty((g, nq, k), dtype=torch.int64, device=dev)
+    all_s = torch.empty((g, nq, k), dtype=torch.float32, device=dev)
+    for r in range(g):
+        vb = B.VerticalBatch.generate(n, dim, seed=0, row0=r * n, ctx=ctx)
+        vb.set_index_base(r * n)
+        st = innr.KnnStats()
+        idx, sc = _gpu_local_search(vb, innr.METRIC_COSINE, innr.KNN_MFMA)(q_dev, k, st)
+        torch.cuda.synchronize()
+        assert st.engine == innr.KNN_MFMA and st.queries_fallback <= 8, st.queries_fallback
+        print(f"C5 shard {r}: cosine 4096 q x 10M x 768: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, "
+              f"fallback {st.queries_fallback}")
+        all_i[r], all_s[r] = idx, sc
+        hi, hs = idx.cpu().numpy(), sc.cpu().numpy()
+        assert hi.min() >= r * n and hi.max() < (r + 1) * n
+        assert np.all(hs[:, :-1] >= hs[:, 1:]) and all(len(set(row.tolist())) == k for row in hi)
+        mine = (picks // n) == r  # queries that are rows of THIS shard: self-match first, cosine ~ 1
+        assert np.array_equal(hi[mine, 0], picks[mine]) and np.all(np.abs(hs[mine, 0] - 1.0) < 1e-5)
+        sub = np.arange(0, nq, 293)[:14]  # 14 queries spread over the batch (two 8-query passes of the exact engine)
+        ei, es = _gpu_local_search(vb, innr.METRIC_COSINE, innr.KNN_EXACT)(q_dev[torch.from_numpy(sub).to(dev)].contiguous(), k)
+        assert np.array_equal(hi[sub], ei.cpu().numpy()) and bits_equal(hs[sub], es.cpu().numpy())
+        vb.close()
+    out_i, out_s = _gpu_merge(ctx, innr.METRIC_COSINE)(all_i, all_s, k)
+    torch.cuda.synchronize()
+    out_i, out_s = out_i.cpu().numpy(), out_s.cpu().numpy()
+    ci = all_i.cpu().numpy().transpose(1, 0, 2).reshape(nq, g * k)
+    cs = all_s.cpu().numpy().transpose(1, 0, 2).reshape(nq, g * k)
+    order = np.lexsort((ci, -cs.astype(np.float64)), axis=1)[:, :k]  # score descending, then global index ascending
+    assert np.array_equal(out_i, np.take_along_axis(ci, order, 1)) and bits_equal(out_s, np.take_along_axis(cs, order, 1))
+    assert np.array_equal(out_i[:, 0], picks) and np.all(np.abs(out_s[:, 0] - 1.0) < 1e-5)
+    ctx.close()
+
+
 @pytest.mark.parametrize("waves", ["4", "8"])
 def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves, monkeypatch):
     # plan_gemm picks 8-wave (512-query) tiles for dot and 4-wave tiles for cosine / L2; INNR_GEMM_WAVES forces either,

@@ -40,7 +40,17 @@ def test_logical_shards_merge_equals_whole_corpus(metric_name, g, n_total, k):
         all_s[r, :, :sc.shape[1]] = sc
     kout = min(k, n_total)
     out_i, out_s = _gpu_merge(ctx, metric)(all_i, all_s, kout)
+    # the exchange format of the library's own sharded call (innr_topk_pack_dev -> [all-gather] -> innr_merge_blocks_dev):
+    # one block of 2 + Q*k words per shard, 8 bytes per candidate; here the "gather" is a torch.stack
+    from innr_amd.dist import gpu_merge_blocks, gpu_pack_block
+    blocks = []
+    for r in range(g):
+        start, count = shard_range(n_total, g, r)
+        kk = min(k, count)
+        blocks.append(gpu_pack_block(ctx, all_i[r, :, :kk].contiguous(), all_s[r, :, :kk].contiguous(), start, count, k))
+    b_i, b_s = gpu_merge_blocks(ctx, metric, torch.stack(blocks), nq, k)
     torch.cuda.synchronize()
+    assert b_i.shape == (nq, kout) and torch.equal(b_i, out_i) and torch.equal(b_s.view(torch.int32), out_s.view(torch.int32))
     out_i, out_s = out_i.cpu().numpy(), out_s.cpu().numpy()
     data = oracle.from_rows(oracle.generate_uniform(n_total, dim, 7))
     ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine, "l2": oracle.batch_knn}[metric_name]
@@ -114,4 +124,61 @@ def test_logical_shards_u8_and_maxsim():
     for o in keep:
         o.close()
     whole.close()
+    ctx.close()
+
+
+def test_rccl_exchange_behind_the_abi_world_1():
+    """The library's own exchange step on a real RCCL communicator: innr_comm_unique_id / innr_comm_create (world = 1:
+    the one-GPU box; RCCL refuses two ranks per device) and innr_sharded_knn_dev = local search + pack + ncclAllGather +
+    merge -- for an f32 shard and a u8 code shard, against the plain local search and the oracle."""
+    import torch
+    import innr_amd
+    from innr_amd import batch as B
+    from innr_amd import scalar as S
+    from innr_amd.dist import Comm, ShardedKnn, _gpu_local_search
+
+    ctx = innr_amd.Context(0)
+    dev = torch.device("cuda", 0)
+    comm = Comm(ctx, 0, 1, Comm.unique_id())
+    n, dim, nq, k = 30_000, 40, 37, 12
+    queries = oracle.generate_uniform(nq, dim, 99)
+    q_dev = torch.from_numpy(queries).to(dev)
+    vb = B.VerticalBatch.generate(n, dim, seed=7, row0=0, ctx=ctx)
+    data = oracle.from_rows(oracle.generate_uniform(n, dim, 7))
+    for metric, ofn in ((innr_amd.METRIC_DOT, oracle.batch_knn_dot), (innr_amd.METRIC_COSINE, oracle.batch_knn_cosine),
+                        (innr_amd.METRIC_L2SQ, oracle.batch_knn)):
+        sk = ShardedKnn(n, rank=0, world=1, comm=comm)
+        sk.attach_gpu_batch(vb, metric)
+        st = innr_amd.KnnStats()
+        idx, sc = sk.search(q_dev, k, st)
+        torch.cuda.synchronize()
+        assert idx.shape == (nq, k) and st.total_ms > 0
+        for j in range(nq):
+            oi, os_ = ofn(queries[j], data, k)
+            assert idx[j].cpu().numpy().tolist() == oi.astype(np.int64).tolist()
+            assert np.array_equal(sc[j].cpu().numpy().view(np.uint32), os_.view(np.uint32))
+    # k larger than the shard: k' = min(k, total)
+    small = B.VerticalBatch.generate(5, dim, seed=7, row0=0, ctx=ctx)
+    sk = ShardedKnn(5, rank=0, world=1, comm=comm)
+    sk.attach_gpu_batch(small, innr_amd.METRIC_DOT)
+    idx, sc = sk.search(q_dev, 9)
+    assert idx.shape == (nq, 5) and sorted(idx[0].cpu().tolist()) == [0, 1, 2, 3, 4]
+    # u8 codes
+    p = S.QuantizationParams.from_range(-1.0, 1.0)
+    qc = S.QuantizedCorpus.generate(n, dim, p, seed=4, row0=0, ctx=ctx)
+    sk = ShardedKnn(n, rank=0, world=1, comm=comm)
+    sk.attach_gpu_u8(qc)
+    idx, sc = sk.search(q_dev, k)
+    torch.cuda.synchronize()
+    codes = oracle.quantize_u8(oracle.generate_uniform(n, dim, 4), oracle.QParams(p.alpha, p.offset))
+    for j in range(0, nq, 5):
+        oi, os_ = oracle.batch_knn_u8(queries[j], codes, oracle.QParams(p.alpha, p.offset), k)
+        assert idx[j].cpu().numpy().tolist() == oi.astype(np.int64).tolist()
+        assert np.array_equal(sc[j].cpu().numpy().view(np.uint32), os_.view(np.uint32))
+    # a dimension mismatch is reported like the local call's (before anything is exchanged)
+    with pytest.raises(innr_amd.InnrPanic):
+        sk.search(torch.zeros((2, dim + 1), device=dev), k)
+    comm.close()
+    for o in (vb, small, qc):
+        o.close()
     ctx.close()

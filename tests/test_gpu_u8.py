@@ -133,7 +133,8 @@ def test_device_quantize_and_fit_match_host(S, innr):
 
 
 @pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
-@pytest.mark.parametrize("n,dim,nq,kc,k", [(2000, 48, 7, 40, 10), (500, 16, 3, 256, 256), (9000, 128, 20, 100, 100)])
+@pytest.mark.parametrize("n,dim,nq,kc,k", [(2000, 48, 7, 40, 10), (500, 16, 3, 256, 256), (9000, 128, 20, 100, 100),
+                                           (3000, 24, 5, 257, 20), (3000, 24, 4, 2500, 2500), (700, 8, 3, 700, 10**6)])
 def test_batch_rerank_matches_oracle(innr, metric, n, dim, nq, kc, k):
     from innr_amd import batch as B
     rows = oracle.generate_uniform(n, dim, 12)
@@ -154,6 +155,11 @@ def test_batch_rerank_matches_oracle(innr, metric, n, dim, nq, kc, k):
         assert idx[j].tolist() == c[order].tolist() and bits_equal(sc[j], s[order]), (metric, j)
     with pytest.raises(innr.InnrError):
         B.batch_rerank(qs, vb, np.full((nq, 4), n + 5, np.uint64), 2, met)  # outside the batch
+    if kc > 256:  # the sorted path flags out-of-range candidates too
+        bad = cand.copy()
+        bad[0, 5] = n + 1
+        with pytest.raises(innr.InnrError):
+            B.batch_rerank(qs, vb, bad, 2, met)
 
 
 def test_two_stage_pipeline_u8_then_exact(S, innr):
@@ -216,8 +222,8 @@ def test_rerank_and_ingest_edge_cases(S, innr):
     assert idx.shape[1] == 0
     with pytest.raises(innr.InnrPanic):
         B.batch_rerank(np.ones((2, 9), np.float32), vb, np.array([[1], [2]], np.uint64), 1)  # dimension mismatch
-    with pytest.raises(innr.InnrError):
-        B.batch_rerank(q, vb, np.zeros((2, 300), np.uint64), 1)  # more than 256 candidates
+    idx, sc = B.batch_rerank(q, vb, np.zeros((2, 300), np.uint64), 1)  # more than 256 candidates (here: all the same one)
+    assert idx.tolist() == [[0], [0]]
     # index base: candidates are GLOBAL indices
     vb.set_index_base(1000)
     idx, sc = B.batch_rerank(q[:1], vb, np.array([[1007, 1003]], np.uint64), 2)

@@ -8,7 +8,14 @@ the ISA (`make -C innr_amd/csrc asm`) and fails unless, in every instantiation, 
 only by: the asm loads themselves, MFMAs, their zero-initialisation, and address temporaries that feed the very next
 load of the same pair.
 
+A second check covers the hazard behind the one GPU memory fault this code has had: a VALU-written SGPR pair (a reloaded
+spill, a v_readfirstlane) read as the BASE of a VMEM instruction needs wait states that hipcc does not insert in front of
+inline asm. Every asm load therefore copies its base with `s_mov_b64` inside the same statement (SALU reads are
+interlocked); the script fails if any `global_load*` inside an ;;#ASMSTART block takes a base that the block did not
+just write with s_mov_b64.
+
     make -C innr_amd/csrc asm && python tools/check_gemm_asm.py
+(also run by __graft_entry__.build() and tests/test_abi.py::test_gemm_asm_guard, both on the CPU box)
 """
 import os
 import re
@@ -17,13 +24,33 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
 s = open(path).read()
-names = [n for n in re.findall(r"^(_ZN4innr(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel)\S+):", s, flags=re.M) if not n.endswith(".kd")]
+KERNELS = r"(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel|21gemm_i8_filter_kernel)"
+names = [n for n in re.findall(r"^(_ZN4innr" + KERNELS + r"\S+):", s, flags=re.M) if not n.endswith(".kd")]
 if not names:
     sys.exit("no gemm_filter_kernel in " + path)
 bad_total = 0
 for name in names:
     i = s.index("\n" + name + ":")
     body = s[i:s.index("s_endpgm", i)].split("\n")
+    # hazard check: inside every asm block, the SGPR base of a global load must have been written by an s_mov_b64 of the
+    # same block (never a register the compiler may have produced on the VALU right before the statement)
+    unsafe = []
+    k = 0
+    while k < len(body):
+        if ";;#ASMSTART" in body[k]:
+            j = k + 1
+            moved = set()
+            while j < len(body) and ";;#ASMEND" not in body[j]:
+                t = body[j].split(";")[0].strip()
+                m = re.match(r"s_mov_b64 (s\[\d+:\d+\]),", t)
+                if m:
+                    moved.add(m.group(1))
+                m = re.match(r"global_load\S* .*?(s\[\d+:\d+\])", t)
+                if m and m.group(1) not in moved:
+                    unsafe.append(t)
+                j += 1
+            k = j
+        k += 1
     pairs = set()
     for k, line in enumerate(body):
         if ";;#ASMSTART" in line:
@@ -73,9 +100,11 @@ for name in names:
             bad.append(t)
     short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3,\4>", name)
     short = re.sub(r".*gemm_bf16_filter_kernelILi(\d+)ELi(\d+)E.*", r"bf16<\1,\2>", short)
-    status = "ok" if (len(pairs) == 8 and not bad) else "FAIL"
-    print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads  {status}")
-    for b in bad[:5]:
+    short = re.sub(r".*gemm_i8_filter_kernelILi(\d+)ELi(\d+)E.*", r"i8<\1,\2>", short)
+    want_pairs = 16 if "gemm_i8_filter_kernel" in name else 8  # the int8 kernel carries two limbs per operand
+    status = "ok" if (len(pairs) == want_pairs and not bad and not unsafe) else "FAIL"
+    print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads, {len(unsafe)} asm loads without s_mov_b64 base  {status}")
+    for b in (bad + unsafe)[:5]:
         print("     ", b)
-    bad_total += (len(pairs) != 8) + len(bad)
+    bad_total += (len(pairs) != want_pairs) + len(bad) + len(unsafe)
 sys.exit(1 if bad_total else 0)

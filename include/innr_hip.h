@@ -55,6 +55,13 @@ typedef int innr_status;
                               * bf16 error bound, unproven queries are redone exactly. Dot metric with k <= 48; every other
                               * call is served by INNR_KNN_MFMA (innr_knn_stats.engine tells). Not chosen by INNR_KNN_AUTO. */
 
+#define INNR_KNN_MFMA_I8 4 /* innr_batch_knn_u8[_dev] only: the filter on the INTEGER matrix pipe (v_mfma_i32_32x32x32_i8, 32x the f32
+                            * MFMA rate) over a K-packed signed copy of the codes built on first use (+ N*D bytes of HBM), the f32
+                            * query as two int8 limbs of a 16-bit fixed-point value. Results unchanged: candidates are re-scored in
+                            * the reference's f32 order and proven against the quantisation bound, unproven queries redone exactly.
+                            * Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call (stats->engine tells).
+                            * INNR_KNN_AUTO picks it for query batches on large code corpora. */
+
 #define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). Every kNN entry point accepts
                         * any k, like the reference: beyond INNR_MAX_K innr_batch_knn[_dev], innr_batch_knn_u8[_dev],
                         * innr_batch_knn_filtered / _reordered compute all N scores and sort them on the device, one query

@@ -6,8 +6,8 @@ function surface over a C ABI (include/innr_hip.h); device side = hand-written H
 (innr_amd/csrc). No CPU fallback: importing works without a GPU, computing does not.
 """
 from . import _lib
-from ._lib import (GEN_EXAMPLE_LCG, GEN_UNIFORM, KNN_AUTO, KNN_EXACT, KNN_MFMA, KNN_MFMA_BF16, METRIC_COSINE, METRIC_DOT, METRIC_L2SQ, Context, InnrError,
+from ._lib import (GEN_EXAMPLE_LCG, GEN_UNIFORM, KNN_AUTO, KNN_EXACT, KNN_MFMA, KNN_MFMA_BF16, KNN_MFMA_I8, METRIC_COSINE, METRIC_DOT, METRIC_L2SQ, Context, InnrError,
                    InnrPanic, KnnStats, default_context)
 
-__all__ = ["_lib", "Context", "InnrError", "InnrPanic", "KnnStats", "default_context", "KNN_AUTO", "KNN_EXACT",
+__all__ = ["_lib", "Context", "InnrError", "InnrPanic", "KnnStats", "default_context", "KNN_AUTO", "KNN_EXACT", "KNN_MFMA_I8",
            "KNN_MFMA", "KNN_MFMA_BF16", "METRIC_DOT", "METRIC_L2SQ", "METRIC_COSINE", "GEN_EXAMPLE_LCG", "GEN_UNIFORM"]

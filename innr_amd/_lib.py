@@ -33,6 +33,7 @@ KNN_AUTO = 0
 KNN_EXACT = 1
 KNN_MFMA = 2
 KNN_MFMA_BF16 = 3  # bf16 filter + exact f32 re-score (dot, k <= 48); same results
+KNN_MFMA_I8 = 4  # u8 code corpora: int8-MFMA filter (two int8 limbs per query value) + exact f32 re-score; same results
 
 MAX_K = 240
 

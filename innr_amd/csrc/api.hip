@@ -19,6 +19,7 @@
 #include "kernels_gemm_bf16.h"
 #include "kernels_ext.h"
 #include "kernels_u8.h"
+#include "kernels_gemm_i8.h"
 #include "kernels_maxsim.h"
 
 namespace innr {  // sort_full.hip
@@ -177,6 +178,9 @@ struct innr_batch {
     // bf16 filter engine (kernels_gemm_bf16.h): K-packed bf16 copy of the corpus, built on first use, always owned
     char* Ab = nullptr;
     uint32_t ab_nk = 0;
+    // int8 filter engine (kernels_gemm_i8.h): K-packed signed copy of the u8 codes, built on first use, always owned
+    char* Ai8 = nullptr;
+    uint32_t ai8_nk = 0;
 };
 
 namespace innr {
@@ -1035,6 +1039,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->sqn) (void)hipFree(b->sqn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
     if (b->Ab) (void)hipFree(b->Ab);
+    if (b->Ai8) (void)hipFree(b->Ai8);
     delete b;
 }
 
@@ -1419,6 +1424,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
+    if (engine == INNR_KNN_MFMA_I8) engine = INNR_KNN_MFMA;  // the int8 filter is the code corpora's (innr_batch_knn_u8)
     if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
@@ -1854,6 +1860,167 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
     return redo_batch_u8(b, dQ, qsum, redo, kout, d_out_idx, d_out_score);
 }
 
+// ---- int8 filter engine (kernels_gemm_i8.h) -------------------------------------------------------------------------
+static uint32_t i8_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 128) / 64); }  // K-steps of 64, even
+
+static bool i8_eligible(const innr_batch* b, size_t Q) {
+    return b->C8 && b->alpha > 0.0f && (b->alpha - b->alpha == 0.0f) && (b->offset - b->offset == 0.0f) && b->D >= 1 &&
+           b->D <= 65535 && i8_limb_r1((uint32_t)b->D) >= 1 && b->ldN < ((size_t)1 << 31) && Q < ((size_t)1 << 24);
+}
+
+static innr_status ensure_i8_corpus(innr_batch* b) {
+    if (b->Ai8) return INNR_OK;
+    const uint32_t nk = i8_nk(b);
+    const size_t ntiles = b->ldN / 128, bytes = ntiles * nk * (size_t)kI8StageBytes;
+    hipError_t e = hipMalloc((void**)&b->Ai8, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for the int8 corpus copy failed: %s", bytes, hipGetErrorString(e));
+        b->Ai8 = nullptr;
+        return INNR_E_OOM;
+    }
+    const size_t nthreads = ntiles * nk * 128;
+    pack_corpus_i8_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, b->ctx->stream>>>(b->C8, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk,
+                                                                                      nthreads, reinterpret_cast<uint4*>(b->Ai8));
+    INNR_HIP_CHECK(hipGetLastError());
+    b->ai8_nk = nk;
+    return INNR_OK;
+}
+
+struct I8Plan {
+    size_t Qpad;
+    uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
+};
+static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
+    I8Plan p;
+    p.Qpad = round_up(Q, kI8BQ);
+    p.nqt = (uint32_t)(p.Qpad / kI8BQ);
+    p.KP = pick_kp(kout, 16);
+    p.cap = (uint32_t)cand_cap((int)p.KP);
+    p.ntiles = (uint32_t)(b->ldN / 128);
+    const uint32_t target = std::max(1u, (uint32_t)b->ctx->num_cus / p.nqt);  // one 8-wave block per CU
+    uint32_t ns = std::max(8u, target / 8 * 8);
+    ns = std::min(ns, (uint32_t)round_up(p.ntiles, 8));
+    p.nslices = ns;
+    p.tps = (p.ntiles + ns - 1) / ns;
+    p.nblocks = p.nqt * ns;
+    p.qtg = p.nqt;  // one query tile per XCD group where the tile count allows it (see plan_gemm)
+    for (uint32_t g = 1; g <= p.nqt; ++g)
+        if (p.nqt % g == 0 && 8 % (p.nqt / g) == 0) {
+            p.qtg = g;
+            break;
+        }
+    return p;
+}
+
+template <int MODE>
+static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, const float* qc, float* dump, size_t ld_dump) {
+    innr_ctx* c = b->ctx;
+    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
+    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
+    INNR_TRY(c->gthr.ensure(gbytes));
+    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
+    uint32_t* gslots = c->gthr.as<uint32_t>();
+#define INNR_I8_LAUNCH(RR)                                                                                                  \
+    gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(                                             \
+        b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc,                  \
+        c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump)
+    if constexpr (MODE == 1) {
+        INNR_I8_LAUNCH(6);
+    } else {
+        switch (p.cap) {
+            case 384: INNR_I8_LAUNCH(6); break;
+            case 512: INNR_I8_LAUNCH(8); break;
+            case 768: INNR_I8_LAUNCH(12); break;
+            default: INNR_I8_LAUNCH(20); break;
+        }
+    }
+#undef INNR_I8_LAUNCH
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// queries -> two int8 limbs + per-query constants: Bq in c->q_bf16, qc[4][Qpad] at c->misc
+static innr_status prep_queries_i8(innr_batch* b, const I8Plan& p, const float* dQ, size_t Q, const float* qsum) {
+    innr_ctx* c = b->ctx;
+    INNR_TRY(c->q_bf16.ensure((size_t)b->ai8_nk * 8 * p.Qpad * 16));
+    INNR_TRY(c->misc.ensure(4 * p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
+    pack_queries_i8_kernel<<<(unsigned)p.Qpad, 64, 0, c->stream>>>(dQ, qsum, (uint32_t)Q, (uint32_t)b->D, b->ai8_nk, (uint32_t)p.Qpad,
+                                                                   i8_limb_r1((uint32_t)b->D), b->alpha / 255.0f, b->offset,
+                                                                   reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// int8-MFMA filter + exact re-score + proof; same contract as knn_u8_mfma
+static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t kout, const float* qsum, const float* qnorm,
+                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms) {
+    innr_ctx* c = b->ctx;
+    INNR_TRY(ensure_i8_corpus(b));
+    const I8Plan p = plan_i8(b, Q, kout);
+    INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum));
+    const float* qc = c->misc.as<float>();
+    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 4 * p.Qpad * sizeof(float));
+    INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY(launch_gemm_i8<0>(b, p, qc, nullptr, 0));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
+    const float a255 = b->alpha / 255.0f;
+    // the reference's own f32 accumulation against the true sum: (D + 2) u ||q|| max||c||, ||c|| <= 255 sqrt(D) (the bound of
+    // knn_u8_mfma, whose MFMA-chain half is simply unused here); the query's quantisation share comes per query (qc[3])
+    const float err_scale = 1.05f * fabsf(a255) * (2.0f * (float)b->D + 12.0f) * 5.9604645e-08f * 255.0f * sqrtf((float)b->D);
+#define INNR_RESCORE_U8(RKV)                                                                                          \
+    rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
+                                                              c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
+                                                              (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
+                                                              d_out_score, fallback, qc + 3 * p.Qpad)
+    if (p.KP <= 64) INNR_RESCORE_U8(1);
+    else if (p.KP <= 128) INNR_RESCORE_U8(2);
+    else INNR_RESCORE_U8(4);
+#undef INNR_RESCORE_U8
+    INNR_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> fb(Q);
+    INNR_HIP_CHECK(copy_out(c, fb.data(), fallback, Q * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
+    std::vector<uint32_t> redo;
+    for (size_t q = 0; q < Q; ++q)
+        if (fb[q]) redo.push_back((uint32_t)q);
+    *nfallback = (uint32_t)redo.size();
+    *kept = p.KP;
+    return redo_batch_u8(b, dQ, qsum, redo, kout, d_out_idx, d_out_score);
+}
+
+// Test hook (not part of the ABI): dense approximate score matrix of the int8 engine, out[q*N + i] = A_q V(q, i) + B_q, and
+// the per-query constants qc[4][Qpad] -- to check the int8 MFMA operand layout and the limb arithmetic exactly.
+extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, size_t Q, size_t D, float* out, float* qc_out,
+                                         size_t* qpad_out) {
+    if (!b || !b->C8 || !queries || !out || D != b->D || Q == 0 || b->N == 0 || !i8_eligible(b, Q)) return INNR_E_BAD_ARG;
+    innr_ctx* c = b->ctx;
+    INNR_ENTER(c);
+    INNR_TRY(ensure_i8_corpus(b));
+    const I8Plan p = plan_i8(b, Q, 1);
+    INNR_TRY(c->q_row.ensure(Q * D * sizeof(float)));
+    INNR_TRY(c->q_norm.ensure(2 * p.Qpad * sizeof(float)));
+    INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
+    float* qsum = c->q_norm.as<float>();
+    query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(c->q_row.as<float>(), (uint32_t)Q, (uint32_t)D, D, qsum, qsum + p.Qpad);
+    INNR_TRY(prep_queries_i8(b, p, c->q_row.as<float>(), Q, qsum));
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
+    INNR_TRY(launch_gemm_i8<1>(b, p, c->misc.as<float>(), c->scores.as<float>(), b->ldN));
+    INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float), b->N * sizeof(float), Q,
+                                    hipMemcpyDeviceToHost, c->stream));
+    if (qc_out) INNR_HIP_CHECK(hipMemcpyAsync(qc_out, c->misc.p, 4 * p.Qpad * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (qpad_out) *qpad_out = p.Qpad;
+    INNR_HIP_CHECK(ctx_sync(c));
+    return INNR_OK;
+}
+
 innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t Q, size_t D, size_t k, int engine,
                                   uint64_t* d_out_idx, float* d_out_score, size_t* out_k, innr_knn_stats* stats) {
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -1873,14 +2040,20 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     float* qnorm = qsum + round_up(Q, kBQmax);
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D, qsum, qnorm);
     INNR_HIP_CHECK(hipGetLastError());
-    if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
-    if (engine == INNR_KNN_MFMA_BF16) engine = INNR_KNN_MFMA;  // codes are widened on the f32 pipe: no bf16 variant
+    if (engine == INNR_KNN_AUTO) {
+        engine = innr_batch_auto_engine(b, Q);
+        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !getenv("INNR_U8_NO_I8")) engine = INNR_KNN_MFMA_I8;
+    }
+    if (engine == INNR_KNN_MFMA_BF16) engine = INNR_KNN_MFMA;  // codes are exact in 8 bits: the low-precision filter is the int8 one
+    if (engine == INNR_KNN_MFMA_I8 && !i8_eligible(b, Q)) engine = INNR_KNN_MFMA;  // alpha <= 0 / non-finite params / D beyond the limbs
     if (engine == INNR_KNN_MFMA && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;
     uint32_t nfallback = 0, kept = kout > INNR_MAX_K ? (uint32_t)b->N : pick_kp(kout, 0);
     float gemm_ms = 0.0f;
     if (kout > INNR_MAX_K) {
         INNR_TRY(knn_full_sort(b, -1, d_queries, D, qsum, Q, kout, d_out_idx, d_out_score));
+    } else if (engine == INNR_KNN_MFMA_I8) {
+        INNR_TRY(knn_u8_i8(b, d_queries, Q, kout, qsum, qnorm, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
     } else if (engine == INNR_KNN_MFMA) {
         INNR_TRY(knn_u8_mfma(b, d_queries, Q, kout, qsum, qnorm, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms));
     } else {

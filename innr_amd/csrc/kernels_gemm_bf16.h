@@ -210,7 +210,11 @@ __global__ __launch_bounds__(64 * kBfWaves, 1) void gemm_bf16_filter_kernel(
             b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
             // nk is a multiple of kBfLead, so a tile always ends on the last ring position: ONE copy of the epilogue in
             // the unrolled loop (two copies made the kernel 81 KB, more than the 64 KB instruction cache)
+#ifdef INNR_GEMM_PROBE_SKIPEPI  // tools/bf16_epi_probe.hip: the same code, the epilogue never taken (dump == nullptr at run time)
+            if (r == kBfLead - 1 && ks + 1 == nk && dump != nullptr) {
+#else
             if (r == kBfLead - 1 && ks + 1 == nk) {
+#endif
 #include "gemm_epilogue.inc"
                 ks = 0;
                 ++tile;

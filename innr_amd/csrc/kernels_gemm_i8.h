@@ -1,0 +1,402 @@
+// kernels_gemm_i8.h -- scalar::batch_knn_u8 (src/scalar.rs:370-393) with the FILTER on the integer matrix pipe:
+// v_mfma_i32_32x32x32_i8, twice the bf16 MFMA rate, 32x the f32 MFMA rate the "path B" kernel (kernels_gemm.h, kGemmU8) runs at.
+//
+// Reference hot loop: mixed_dot_u8_f32_portable (scalar.rs:353-358), sum_d q_d * (c_d as f32), driven per document by
+// asymmetric_dot_u8_precomputed (:284-300) inside batch_knn_u8 (:370-393).
+//
+// The corpus side is already 8-bit: c' = c - 128 (one XOR) is an exact i8. The f32 query becomes a 16-bit fixed-point
+// number per dimension, t_d = round(q_d / s_j) with one scale s_j = max|q_d| / T per query, split into two i8 LIMBS
+// t = 256 r1 + r2 (r2 in [-128,127], |r1| <= R1). Two integer GEMMs over the same corpus tile, hi = sum c' r1 and
+// lo = sum c' r2, give V = 256 hi + lo = sum_d c'_d t_d EXACTLY (T is chosen so that |V| < 2^31), and
+//     approx(j, i) = A_j V + B_j,   A_j = (alpha/255) s_j,   B_j = (128 alpha/255 + offset) sum(q_j)
+// differs from the reference's score only by the query's quantisation, |alpha/255| (s_j/2) sum_d |c'_d| <= |alpha/255| s_j 64 D,
+// and float rounding: ~1e-3 of the gap between neighbouring top scores at C3. The approximate scores are only a FILTER
+// (like gemm_filter_kernel's): candidates go into the same per-(slice, query) lists, the caller re-scores them in the
+// reference's f32 order (rescore_u8_kernel) and proves the answer against that bound; unproven queries are redone exactly.
+//
+// Layouts (built once per corpus / once per call by the pack kernels below):
+//   corpus  Ai8[tile][ks][kg 0..3][rt 0..3][i 0..31][16 i8]   corpus row = 128 tile + 4 i + rt, dimension = 64 ks + 16 kg + e
+//           one K-step (64 dimensions) of a 128-row tile is 8 KiB contiguous = eight 1-KiB LDS-DMA pieces, one per wave;
+//           an A fragment (row i of row tile rt, 16 consecutive k) is one conflict-free ds_read_b128.
+//   queries Bq[ks][kg 0..3][limb 0..1][query 0..Qpad)[16 i8]   one 16-byte load per lane and fragment, straight from L2.
+//   (The hardware's k order inside a 32-deep MFMA step is the same for the A and the B operand, and the sum over k does
+//    not depend on it: both sides are packed "lane half h holds dimensions 16 (2 m + h) .. + 15 of depth m".)
+// Block = 8 waves; tile 128 corpus rows x 256 queries: wave w owns queries [32 w, 32 w + 32) x 128 rows x both limbs =
+// 4 x 2 accumulator tiles of 32 x 32 i32 (128 VGPRs), so a lane holds 64 corpus rows of ONE query. The K-loop is
+// gemm_bf16_filter_kernel's: LDS ring of 8 stages, DMA six steps ahead, query fragments two steps ahead in a register
+// ring, one barrier per K-step, every step the same VMEM sequence (1 DMA + 2 x 2 fragment loads) with hand-counted waits.
+// Roofline: integer MFMA; algorithmic ops 2 Q N D (x 2 limbs executed); corpus bytes N D per 256 queries.
+#pragma once
+
+#include "kernels_gemm_bf16.h"
+#include "kernels_u8.h"
+
+namespace innr {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr int kI8Stages = 8, kI8Lead = 2, kI8StageBytes = 8192, kI8Waves = 8, kI8K = 64, kI8BQ = 256;
+
+// largest 16-bit-fixed-point magnitude T = 256 R1 + 127 such that |V| <= D * 128 * T stays below 2^31
+__host__ __device__ inline uint32_t i8_limb_r1(uint32_t D) {
+    const uint64_t tmax = (((uint64_t)1 << 31) - 1) / ((uint64_t)(D ? D : 1) * 128);
+    if (tmax < 127 + 256) return 0;  // not even one step of the high limb: the engine is off for this dimension
+    const uint64_t r1 = (tmax - 127) / 256;
+    return (uint32_t)(r1 > 127 ? 127 : r1);
+}
+
+// PDX codes C8[d*ldN + i] -> Ai8. One thread per (tile, ks, kg, i): 16 dimensions x 4 consecutive corpus rows (rows 4i .. 4i+3 of
+// the tile are the four row tiles rt), read as 16 coalesced dwords, written as four 16-byte units.
+__global__ __launch_bounds__(256) void pack_corpus_i8_kernel(const uint8_t* __restrict__ C8, size_t ldN, uint32_t N, uint32_t D,
+                                                              uint32_t nk, size_t nthreads, uint4* __restrict__ Ai8) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nthreads) return;
+    const uint32_t i = (uint32_t)(t & 31), kg = (uint32_t)((t >> 5) & 3);
+    const size_t tk = t >> 7;  // tile * nk + ks
+    const uint32_t ks = (uint32_t)(tk % nk);
+    const size_t row0 = (tk / nk) * 128 + 4 * (size_t)i;  // < ldN (ldN is a multiple of 1024)
+    uint32_t w[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const uint32_t d = ks * 64 + kg * 16 + e;
+        uint32_t v = 0x80808080u;  // code 128 -> c' = 0: padding dimensions contribute nothing
+        if (d < D) v = *reinterpret_cast<const uint32_t*>(C8 + (size_t)d * ldN + row0);
+        w[e] = v ^ 0x80808080u;  // c - 128 as i8, four rows at once
+    }
+    uint4* out = Ai8 + (tk * 4 + kg) * 128 + i;  // + rt * 32
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            uint32_t byte = (w[e] >> (8 * rt)) & 0xffu;
+            if (row0 + rt >= N) byte = 0u;
+            o[e >> 2] |= byte << (8 * (e & 3));
+        }
+        out[rt * 32] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// One wave per query: scale, two limbs per dimension, per-query constants.
+//   qc[0][j] = A_j, qc[1][j] = B_j, qc[2][j] = 1 / A_j, qc[3][j] = the query's share of the proof's error bound:
+//   |approx - (alpha/255 * true mixed dot + offset * sum q)| <= |alpha/255| s_j 64 D (quantisation, sum|c'| <= 128 D) + float
+//   rounding of A V + B (three roundings of values <= |A V| + |B|), with 2 % to spare; +inf when no finite scale exists
+//   (the proof then fails and the query takes the exact engine).
+__global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __restrict__ Qm, const float* __restrict__ qsum, uint32_t Q,
+                                                              uint32_t D, uint32_t nk, uint32_t Qpad, uint32_t R1, float a255,
+                                                              float offset, uint4* __restrict__ Bq, float* __restrict__ qc) {
+    const uint32_t j = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float T = (float)(256u * R1 + 127u);
+    float mx = 0.0f;
+    bool finite = true;
+    if (j < Q)
+        for (uint32_t d = lane; d < D; d += 64) {
+            const float x = Qm[(size_t)j * D + d];
+            finite = finite && (x - x == 0.0f);
+            mx = fmaxf(mx, fabsf(x));
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    finite = __all(finite);
+    float s = mx / T;
+    const bool usable = j < Q && finite && mx > 0.0f && s > 0.0f && (1.0f / s) - (1.0f / s) == 0.0f;
+    if (!usable) s = 1.0f;
+    const float inv_s = 1.0f / s;
+    const uint32_t nchunks = nk * 4;  // 16-dimension chunks
+    for (uint32_t c = lane; c < nchunks; c += 64) {
+        uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t d = c * 16 + e;
+            int t = 0;
+            if (usable && d < D) {
+                float x = rintf(Qm[(size_t)j * D + d] * inv_s);
+                x = fminf(fmaxf(x, -T), T);
+                t = (int)x;
+            }
+            const int r1 = (t + 128) >> 8;  // floor((t + 128) / 256): |r1| <= R1
+            const int r2 = t - 256 * r1;    // [-128, 127]
+            hi[e >> 2] |= ((uint32_t)r1 & 0xffu) << (8 * (e & 3));
+            lo[e >> 2] |= ((uint32_t)r2 & 0xffu) << (8 * (e & 3));
+        }
+        // c = ks * 4 + kg
+        Bq[((size_t)c * 2 + 0) * Qpad + j] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        Bq[((size_t)c * 2 + 1) * Qpad + j] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    if (lane == 0) {
+        float A = 1.0f, B = 0.0f, E = 0.0f;
+        if (j < Q) {
+            const float qs = qsum[j];
+            A = a255 * s;
+            B = (128.0f * a255 + offset) * qs;
+            const float vmax = 128.0f * (float)D * T;  // |V| <= this
+            E = usable ? 1.02f * (fabsf(a255) * s * 64.0f * (float)D + 2.4e-7f * (fabsf(A) * vmax + fabsf(B)) +
+                                  2.4e-7f * (fabsf(128.0f * a255 * qs) + fabsf(offset * qs)))
+                       : __builtin_inff();
+            if (!usable && mx == 0.0f && finite) E = 0.0f;  // the zero query: V = 0 and approx = B = exact for every document
+            if (!(A > 0.0f) || !(E - E == 0.0f)) {
+                A = 1.0f;  // never used for ranking claims: E = +inf sends the query to the exact engine
+                E = __builtin_inff();
+            }
+        }
+        qc[j] = A;
+        qc[Qpad + j] = B;
+        qc[2 * (size_t)Qpad + j] = 1.0f / A;
+        qc[3 * (size_t)Qpad + j] = E;
+    }
+}
+
+template <int N> __device__ __forceinline__ void use_after1(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }
+
+struct alignas(16) GemmI8Lds {
+    alignas(16) char A[kI8Stages * kI8StageBytes];
+    uint32_t cnt[kI8BQ];
+    uint32_t thr[kI8BQ];
+};
+
+// MODE 0: fused top-k filter. MODE 1: dump the dense approximate score matrix (layout test).
+template <int R, int MODE>
+__global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
+    const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
+    uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ qc, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
+    uint32_t KP, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    constexpr int kEpiTgWait = 5 * (kI8Stages - 3) + 4 + 5;
+    __shared__ GemmI8Lds s;
+    constexpr uint32_t cap = 64 * R;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    // block -> (slice, query tile): as in gemm_filter_kernel
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7, lb = b >> 3, groups = nqt / qtg;
+    const uint32_t qt = (xcd % groups) * qtg + lb % qtg;
+    const uint32_t slice = (lb / qtg) * (8 / groups) + xcd / groups;
+    const size_t q0 = (size_t)qt * kI8BQ;
+    uint32_t t0 = slice * tiles_per_slice, t1 = t0 + tiles_per_slice;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 > t1) t0 = t1;
+    const uint32_t total = (t1 - t0) * nk;
+
+    if (threadIdx.x < kI8BQ) {
+        s.cnt[threadIdx.x] = 0;
+        s.thr[threadIdx.x] = 0;
+    }
+    uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
+
+    i32x16_t acc[4][2];  // [row tile][limb: 0 = high, 1 = low]
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int L = 0; L < 2; ++L)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[rt][L][g] = 0;
+
+    const int half = lane >> 5, C = lane & 31;
+    const int ql = 32 * w + C;  // this lane's query inside the block tile (lanes l and l + 32 share it)
+    const float Aj = qc[q0 + ql], Bj = qc[Qpad + q0 + ql], invAj = qc[2 * Qpad + q0 + ql];
+
+    // operand addresses: wave-uniform base + constant lane offset
+    const char* sa = Ai8 + (size_t)t0 * nk * kI8StageBytes + (size_t)wu * 1024;  // this wave's 1-KiB piece of step 0
+    const uint32_t va = (uint32_t)lane * 16u;
+    const uint32_t lds0 = lds_addr_uniform(&s.A[0]) + (uint32_t)wu * 1024u;
+    // Bq[ks][kg][limb][Qpad][16]: depth m of a lane half h is kg = 2 m + h
+    const size_t b_step = (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_limb = Qpad * 16;
+    const char* sb = Bq + (q0 + (size_t)wu * 32) * 16;
+    const uint32_t vb = ((uint32_t)half * 2u * (uint32_t)Qpad + (uint32_t)C) * 16u;
+    uint32_t a_issued = 0, b_ks = 0;
+    const uint32_t last = total ? total - 1 : 0;
+    auto issue_a = [&]() {  // DMA of step a_issued; past the end of the slice: the last step again, into a stage nobody reads
+        const uint32_t st = a_issued < total ? a_issued : last;
+        glds16(uniform_ptr(sa + (size_t)st * kI8StageBytes), va, lds0 + (a_issued % kI8Stages) * kI8StageBytes);
+        ++a_issued;
+    };
+    auto issue_b = [&](u32x4_t& dhi, u32x4_t& dlo, int m) {
+        const char* p = uniform_ptr(sb + (size_t)b_ks * b_step + (size_t)m * b_depth);
+        gload4(dhi, p, vb);
+        gload4(dlo, uniform_ptr(p + b_limb), vb);
+    };
+    u32x4_t breg[kI8Lead][4];  // [step % kI8Lead][2 m + limb]
+#pragma unroll
+    for (int r = 0; r < kI8Lead; ++r)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) breg[r][x] = u32x4_t{0u, 0u, 0u, 0u};
+    if (total) {
+        for (int i = 0; i < kI8Stages - 2; ++i) issue_a();
+#pragma unroll
+        for (int r = 0; r < kI8Lead; ++r) {
+            issue_b(breg[r][0], breg[r][1], 0);
+            issue_b(breg[r][2], breg[r][3], 1);
+            b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
+        }
+    }
+    wait_all();
+#pragma unroll
+    for (int r = 0; r < kI8Lead; ++r) {
+        use_after<0>(breg[r][0], breg[r][1]);
+        use_after<0>(breg[r][2], breg[r][3]);
+    }
+    __syncthreads();
+
+    uint32_t tg_next = 0u;
+    if (MODE == 0) gload1_agent(tg_next, gthr + q0 + 32 * wu, 4u * (uint32_t)C);
+    uint32_t tile = t0, ks = 0;
+    for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
+#pragma unroll
+        for (int r = 0; r < kI8Lead; ++r) {  // register ring position = step % kI8Lead: static. nk is even, so total is too.
+            const uint32_t step = step0 + r;
+            const char* stage = s.A + (step % kI8Stages) * kI8StageBytes;
+            issue_a();  // step + kI8Stages - 2
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                i32x4_t a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    a[rt] = *reinterpret_cast<const i32x4_t*>(stage + ((2 * m + half) * 128 + rt * 32 + C) * 16);
+                // ops younger than this depth's operands: see gemm_bf16_filter_kernel (the same VMEM sequence per step)
+                constexpr int kYounger = 5 * kI8Lead - 2;
+                if (m == 0) use_after<kYounger>(breg[r][0], breg[r][1]);
+                else use_after<kYounger>(breg[r][2], breg[r][3]);
+                const i32x4_t bhi = __builtin_bit_cast(i32x4_t, breg[r][2 * m]), blo = __builtin_bit_cast(i32x4_t, breg[r][2 * m + 1]);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], bhi, acc[rt][0], 0, 0, 0);
+                    acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], blo, acc[rt][1], 0, 0, 0);
+                }
+                issue_b(breg[r][2 * m], breg[r][2 * m + 1], m);  // the same registers, kI8Lead steps ahead
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
+            if (r == kI8Lead - 1 && ks + 1 == nk) {
+                // ---------------- epilogue for corpus tile `tile`: one query per lane, 64 corpus rows ----------------
+                const size_t tb = (size_t)tile * 128;
+                // V = 256 hi + lo (exact, |V| < 2^31), kept in the high limb's registers
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[rt][0][g] = (int)(((uint32_t)acc[rt][0][g] << 8) + (uint32_t)acc[rt][1][g]);
+                if (MODE == 1) {
+                    const size_t q = q0 + ql;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            const size_t i = tb + 4 * ((g & 3) + 8 * (g >> 2) + 4 * half) + rt;
+                            dump[q * ld_dump + i] = __builtin_fmaf(Aj, (float)acc[rt][0][g], Bj);
+                        }
+                } else {
+                    use_after1<kEpiTgWait>(tg_next);  // requested a whole tile ago (or before the first K-step)
+                    const uint32_t tl = __hip_atomic_load(&s.thr[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const uint32_t thr = tl > tg_next ? tl : tg_next;
+                    // The fast reject runs on the integers: approx >= thr  =>  V >= Tint, with Tint derived from the float
+                    // threshold conservatively (a lower Tint only sends more sites to the exact float test below).
+                    int32_t Tint = INT32_MIN;  // thr == 0: no bound yet
+                    const float thr_f = ord_f32(thr);
+                    if (thr != 0u) {
+                        const float x = (thr_f - Bj) * invAj;
+                        if (x >= 2.0e9f) Tint = INT32_MAX;
+                        else if (x > -2.0e9f) Tint = (int32_t)__builtin_floorf(x) - 2 - (int32_t)(fabsf(x) * 4.8e-7f);
+                        // x <= -2e9 or NaN: everything passes
+                    }
+                    int32_t gbest[4];
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        int32_t m4 = INT32_MIN;
+#pragma unroll
+                        for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt) m4 = m4 > acc[rt][0][4 * gq + g3] ? m4 : acc[rt][0][4 * gq + g3];
+                        gbest[gq] = m4;
+                    }
+                    const int32_t b01 = gbest[0] > gbest[1] ? gbest[0] : gbest[1], b23 = gbest[2] > gbest[3] ? gbest[2] : gbest[3];
+                    const bool hit = (b01 > b23 ? b01 : b23) >= Tint;
+                    if (__any(hit)) {
+                        uint64_t* lq = my_lists + (size_t)ql * cap;
+                        bool admitted = false;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const bool ghit = hit && gbest[gq] >= Tint;
+                            if (!__any(ghit)) continue;
+                            if (ghit) {
+#pragma unroll
+                                for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                                    for (int rt = 0; rt < 4; ++rt) {
+                                        const int32_t V = acc[rt][0][4 * gq + g3];
+                                        if (V < Tint) continue;
+                                        const uint32_t o = f32_ord(__builtin_fmaf(Aj, (float)V, Bj));
+                                        const size_t i = tb + 4 * (g3 + 8 * gq + 4 * half) + rt;
+                                        if (o >= thr && i < N) {
+                                            admitted = admitted || (((uint32_t)i & (kPubEvery - 1)) == 0);
+                                            cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
+                                            gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
+                                        }
+                                    }
+                            }
+                        }
+                        // re-derive the chip-wide bound of the queries that asked for it (lanes l and l + 32 hold the same query)
+                        unsigned long long m = __ballot(admitted);
+                        m = (m | (m >> 32)) & 0xffffffffull;
+                        while (m) {
+                            const int L = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const size_t qg = q0 + 32 * wu + L;  // wave-uniform
+                            gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // compact the lists of this wave's 32 queries that are running out of room
+                        const uint32_t c = lane < 32 ? __hip_atomic_load(&s.cnt[32 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+                        unsigned long long need = __ballot(c > cap - kGemmBurst);
+                        while (need) {
+                            const int j = __builtin_ctzll(need);
+                            need &= need - 1;
+                            const int qj = 32 * w + j;
+                            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                            uint32_t t;
+                            const uint32_t keep = wave_compact<R>(my_lists + (size_t)qj * cap, cj, KP, &t);
+                            if (lane == 0) {
+                                s.cnt[qj] = keep;
+                                s.thr[qj] = t;
+                                if (t > __hip_atomic_load(&gthr[q0 + qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                    __hip_atomic_fetch_max(&gthr[q0 + qj], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int L = 0; L < 2; ++L)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[rt][L][g] = 0;
+                if (MODE == 0) gload1_agent(tg_next, gthr + q0 + 32 * wu, 4u * (uint32_t)C);
+                ks = 0;
+                ++tile;
+            } else {
+                ++ks;
+            }
+            // this wave's piece of step + 1 (issued kI8Stages - 3 steps ago) has landed; younger ops stay in flight
+            wait_but_youngest<5 * (kI8Stages - 3) + 4>();
+            __syncthreads();
+        }
+    }
+    wait_all();
+    __syncthreads();
+    if (MODE == 0) {
+        const uint32_t c = lane < 32 ? __hip_atomic_load(&s.cnt[32 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+        unsigned long long need = __ballot(c > KP);
+        uint32_t mine = c;
+        while (need) {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)(32 * w + j) * cap, cj, KP, &t);
+            if (lane == j) mine = keep;
+        }
+        if (lane < 32) counts[(size_t)slice * Qpad + q0 + 32 * w + lane] = mine;
+    }
+}
+
+}  // namespace innr

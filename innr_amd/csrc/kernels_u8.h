@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
                                                         const uint64_t* __restrict__ sel, const uint32_t* __restrict__ sel_cnt,
                                                         uint32_t KP, uint32_t kout, float err_scale, uint64_t index_base,
                                                         uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                        uint32_t* __restrict__ fallback) {
+                                                        uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
         const float exact_k = ord_f32(kth_bits);
         const float T = ord_f32(cand_pref(sel[(size_t)q * KP + KP - 1]));
         // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||  +  8u * |offset * sum(q)|
-        const float E = err_scale * qnorm[q] + 4.8e-7f * fabsf(ex::mul(offset, qs));
+        // eq[q] (int8 filter engine): the query's own share of the bound (its 16-bit quantisation), +inf = unprovable
+        const float E = err_scale * qnorm[q] + 4.8e-7f * fabsf(ex::mul(offset, qs)) + (eq ? eq[q] : 0.0f);
         bad = !(exact_k > T + E);
     }
     if (__any(bad) && lane == 0) fallback[q] = 1;

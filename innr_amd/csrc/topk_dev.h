@@ -70,6 +70,13 @@ __device__ __forceinline__ void gthr_raise(uint32_t* slots, uint32_t KP, uint32_
 #define INNR_SLOT_MUL 2
 #endif
 constexpr uint32_t kSlotMul = INNR_SLOT_MUL;
+// A visit of the append path re-derives the chip-wide bound of a query only when it admitted a candidate whose corpus
+// index is a multiple of kPubEvery (a power of two): one admission in kPubEvery, chosen by a property of the data, not of
+// the schedule. Every admission still raises its slot (gthr_raise), so nothing is lost, the published bound just lags.
+#ifndef INNR_PUB_EVERY
+#define INNR_PUB_EVERY 4
+#endif
+constexpr uint32_t kPubEvery = INNR_PUB_EVERY;
 
 // KP-th largest of the S = kSlotMul*KP slot values of one query (wave-uniform arguments), by bisection on the 32 key
 // bits with ballot counts: t = max{x : #(slots >= x) >= KP}; 0 while fewer than KP slots are filled.

@@ -71,15 +71,70 @@ def test_batch_knn_u8_exact_engine(S, innr, n, dim, nq, k):
     assert [r[0] for r in res] == oi.tolist() and bits_equal(np.float32([r[1] for r in res]), os_)
 
 
+def _i8_dense(qc, queries):
+    """test hook (outside include/innr_hip.h): the int8 engine's dense approximate scores + per-query constants"""
+    import ctypes as C
+    from innr_amd import _lib
+    fn = _lib.load().innrdbg_i8_scores
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    q = np.ascontiguousarray(queries, np.float32)
+    nq = q.shape[0]
+    qpad = (nq + 255) // 256 * 256
+    out = np.empty((nq, len(qc)), np.float32)
+    qcst = np.empty((4, qpad), np.float32)
+    got_pad = C.c_size_t(0)
+    _lib.check(fn(qc._h, q.ctypes.data, nq, q.shape[1], out.ctypes.data, qcst.ctypes.data, C.byref(got_pad)))
+    assert got_pad.value == qpad
+    return out, qcst[:, :nq]
+
+
+@pytest.mark.parametrize("n,dim,nq", [(128, 64, 1), (300, 33, 5), (1000, 128, 70), (1025, 200, 300), (3000, 768, 33)])
+def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq):
+    """The int8 MFMA operand layout and the two-limb arithmetic, checked EXACTLY: with s = max|q| / T and t = round(q / s)
+    (T = 256 R1 + 127, R1 from the dimension), the kernel's V must equal sum_d (c_d - 128) t_d as integers -- asymmetric
+    corpus and queries catch a transposed accumulator map or a k-order mismatch between the operands -- and its approximate
+    score A V + B must stay within the engine's own bound E of the reference's asymmetric dot."""
+    alpha, offset = 2.0, -1.0
+    codes = _codes(n, dim, 21, alpha, offset)
+    qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
+    qs = oracle.generate_uniform(nq, dim, 22)
+    qs[0, :] *= np.float32(1e-3)  # a small-magnitude query: its own scale
+    got, (A, Bc, invA, E) = _i8_dense(qc, qs)
+    tmax = (2 ** 31 - 1) // (dim * 128)
+    r1 = min(127, (tmax - 127) // 256)
+    T = np.float32(256 * r1 + 127)
+    a255 = np.float32(alpha) / np.float32(255.0)
+    cp = codes.astype(np.int64) - 128
+    op = oracle.QParams(alpha, offset)
+    for j in range(nq):
+        mx = np.abs(qs[j]).max()
+        s = np.float32(mx) / T
+        t = np.clip(np.rint(qs[j] * (np.float32(1.0) / s)), -T, T).astype(np.int64)
+        V = cp @ t  # exact
+        assert np.abs(V).max() < 2 ** 31
+        assert np.float32(a255 * s).view(np.uint32) == A[j].view(np.uint32)
+        want = (np.float64(A[j]) * V.astype(np.float64) + np.float64(Bc[j])).astype(np.float32)  # one rounding, like the fma
+        ulp = np.spacing(np.abs(want).astype(np.float32))
+        assert np.all(np.abs(got[j].astype(np.float64) - want.astype(np.float64)) <= ulp), j
+        exact = np.array([oracle.asymmetric_dot_u8(qs[j], codes[i], op) for i in range(0, n, max(1, n // 64))], np.float32)
+        sub = got[j][::max(1, n // 64)]
+        assert np.all(np.abs(sub.astype(np.float64) - exact.astype(np.float64)) <= E[j] + 1e-6 * np.abs(exact)), (j, E[j])
+        assert E[j] < 0.01 * (np.abs(exact).max() + 1.0)  # the bound is tiny against the scores (16-bit query values)
+
+
+@pytest.mark.parametrize("engine_name", ["f32-mfma", "int8-mfma"])
 @pytest.mark.parametrize("n,dim,nq,k,alpha,offset", [(300, 16, 20, 10, 2.0, -1.0), (10_000, 128, 100, 10, 2.0, -1.0),
-                                                     (20_000, 96, 300, 100, 3.5, -0.25), (1030, 768, 17, 16, 2.0, -1.0)])
-def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset):
+                                                     (20_000, 96, 300, 100, 3.5, -0.25), (1030, 768, 17, 16, 2.0, -1.0),
+                                                     (70_000, 40, 513, 5, 1.0, 0.0), (5000, 130, 9, 240, 2.0, -1.0)])
+def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_name):
+    engine = {"f32-mfma": innr.KNN_MFMA, "int8-mfma": innr.KNN_MFMA_I8}[engine_name]
     codes = _codes(n, dim, 4, alpha, offset)
     qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
     qs = oracle.generate_uniform(nq, dim, 78)
     st = innr.KnnStats()
-    idx, sc = qc.knn_multi(qs, k, engine=innr.KNN_MFMA, stats=st)
-    assert st.engine == innr.KNN_MFMA
+    idx, sc = qc.knn_multi(qs, k, engine=engine, stats=st)
+    assert st.engine == engine
     for j in range(nq):
         oi, os_ = _oracle_knn(qs[j], codes, alpha, offset, k)
         assert same_knn("dot", idx[j], sc[j], oi, os_), (j, idx[j], oi)
@@ -105,11 +160,36 @@ def test_u8_engines_agree_large(S, innr):
     p = S.QuantizationParams.from_range(-1.0, 1.0)
     qc = S.QuantizedCorpus.generate(2_000_000, 128, p, seed=1)
     qs = oracle.generate_uniform(256, 128, 9)
-    st = innr.KnnStats()
-    i1, s1 = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA, stats=st)
     i2, s2 = qc.knn_multi(qs[:32], 10, engine=innr.KNN_EXACT)
-    assert np.array_equal(i1[:32], i2) and bits_equal(s1[:32], s2)
-    print(f"u8 2Mx128 256q: gemm {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms fallback {st.queries_fallback}")
+    for engine in (innr.KNN_MFMA, innr.KNN_MFMA_I8, innr.KNN_AUTO):
+        st = innr.KnnStats()
+        i1, s1 = qc.knn_multi(qs, 10, engine=engine, stats=st)
+        assert np.array_equal(i1[:32], i2) and bits_equal(s1[:32], s2)
+        assert st.engine == (innr.KNN_MFMA_I8 if engine == innr.KNN_AUTO else engine)  # AUTO: the int8 filter
+        print(f"u8 2Mx128 256q engine {st.engine}: gemm {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms fallback {st.queries_fallback}")
+
+
+def test_i8_engine_special_queries_and_params(S, innr):
+    """zero / tiny / huge / non-finite queries and parameter sets the int8 limbs cannot represent: the answer is the
+    oracle's in every case (unprovable queries take the exact engine; alpha <= 0 is served by the f32 GEMM engine)"""
+    n, dim, k = 70_000, 48, 10
+    codes = _codes(n, dim, 31)
+    qs = oracle.generate_uniform(40, dim, 32)
+    qs[1] = 0.0
+    qs[2] *= np.float32(1e-30)
+    qs[3] *= np.float32(1e30)
+    qs[4, 7] = np.inf
+    qs[5, 0] = np.nan
+    qs[6] = np.float32(0.5)            # constant query: ties everywhere in the quantised domain too
+    qs[7, 1:] = 0.0                    # one non-zero dimension: massive exact ties among codes
+    for alpha, offset in ((2.0, -1.0), (0.5, 3.0), (-2.0, 1.0)):
+        qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
+        st = innr.KnnStats()
+        idx, sc = qc.knn_multi(qs, k, engine=innr.KNN_MFMA_I8, stats=st)
+        assert st.engine == (innr.KNN_MFMA_I8 if alpha > 0 else innr.KNN_MFMA)
+        for j in range(len(qs)):
+            oi, os_ = _oracle_knn(qs[j], codes, alpha, offset, k)
+            assert same_knn("dot", idx[j], sc[j], oi, os_), (alpha, j, idx[j], oi)
 
 
 # ---------------------------------------------------------------- corpus ingest on the device, two-stage pipeline
@@ -183,16 +263,18 @@ def test_two_stage_pipeline_u8_then_exact(S, innr):
         assert all(sc[j][got[i]].view(np.uint32) == es[j][pos[i]].view(np.uint32) for i in common)
 
 
-def test_full_size_properties_c3(S, innr):
-    # BASELINE.json configs[2]: 50M x 768 u8 codes, 1024 queries, k = 100 -- through size-independent properties:
-    # the GEMM engine equals the bit-exact engine on a query subset; results sorted, unique, in range; few redone.
+@pytest.mark.parametrize("engine_name", ["int8-mfma", "f32-mfma"])
+def test_full_size_properties_c3(S, innr, engine_name):
+    # BASELINE.json configs[2]: 50M x 768 u8 codes, 1024 queries, k = 100 ("int8 MFMA") -- through size-independent
+    # properties: the filter engine equals the bit-exact engine on a query subset; results sorted, unique, in range; few redone.
+    engine = {"f32-mfma": innr.KNN_MFMA, "int8-mfma": innr.KNN_MFMA_I8}[engine_name]
     n, dim, nq, k = 50_000_000, 768, 1024, 100
     p = S.QuantizationParams.from_range(-1.0, 1.0)
     qc = S.QuantizedCorpus.generate(n, dim, p, seed=0)
     qs = oracle.generate_uniform(nq, dim, 0xBE7C)
     st = innr.KnnStats()
-    idx, sc = qc.knn_multi(qs, k, engine=innr.KNN_MFMA, stats=st)
-    assert idx.shape == (nq, k) and st.engine == innr.KNN_MFMA and st.queries_fallback <= 8, st.queries_fallback
+    idx, sc = qc.knn_multi(qs, k, engine=engine, stats=st)
+    assert idx.shape == (nq, k) and st.engine == engine and st.queries_fallback <= 8, st.queries_fallback
     assert np.all(sc[:, :-1] >= sc[:, 1:]) and int(idx.max()) < n
     assert all(len(set(r.tolist())) == k for r in idx[::37])
     i2, s2 = qc.knn_multi(qs[:8], k, engine=innr.KNN_EXACT)
@@ -204,7 +286,8 @@ def test_full_size_properties_c3(S, innr):
             row = oracle.generate_uniform(1, dim, 0, row0=int(idx[j, r]))
             code = oracle.quantize_u8(row, op)[0]
             assert np.float32(oracle.asymmetric_dot_u8(qs[j], code, op)).view(np.uint32) == sc[j, r].view(np.uint32)
-    print(f"C3 u8: gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")
+    print(f"C3 u8 ({engine_name}): gemm {st.gemm_ms:.1f} ms, total {st.total_ms:.1f} ms, fallback {st.queries_fallback}")
+    qc.close()
 
 
 def test_rerank_and_ingest_edge_cases(S, innr):

@@ -1,30 +1,54 @@
-"""C3 (BASELINE.json configs[2]): batch_knn_u8 asymmetric, 50M x 768 u8, 1024 queries, k=100, 1 GPU."""
-import os, sys, json
+"""C3 (BASELINE.json configs[2]): batch_knn_u8 asymmetric, 50M x 768 u8, 1024 queries, k=100, 1 GPU.
+
+    python tools/bench_u8.py [N] [engine: i8 | f32]
+
+i8  = INNR_KNN_MFMA_I8: int8-MFMA filter (two int8 limbs per query value) + exact f32 re-score and proof
+f32 = INNR_KNN_MFMA: the codes widened to f32 on the f32 MFMA pipe ("path B")
+Roofline: algorithmic ops 2*Q*N*D against the dense int8 MFMA peak (2x the bf16 one: v_mfma_i32_32x32x32_i8 takes the
+cycles of v_mfma_f32_32x32x16_bf16 at twice the K -- MI355X_MICROARCH.md, Matrix cores) resp. the f32 MFMA peak.
+"""
+import json
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+
 import oracle
-from innr_amd import KNN_EXACT, KNN_MFMA, KnnStats
+from innr_amd import KNN_EXACT, KNN_MFMA, KNN_MFMA_I8, KnnStats
 from innr_amd import scalar as S
 
+PEAK_I8_TOPS = 5032.0   # 256 CU x 4 SIMD x 65536 ops / 32 clk x 2.4 GHz
+PEAK_F32_TFLOPS = 157.3
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+which = sys.argv[2] if len(sys.argv) > 2 else "i8"
+engine = KNN_MFMA_I8 if which == "i8" else KNN_MFMA
 dim, nq, k = 768, 1024, 100
 p = S.QuantizationParams.from_range(-1.0, 1.0)
 qc = S.QuantizedCorpus.generate(n, dim, p, seed=0)
 qs = oracle.generate_uniform(nq, dim, 0xBE7C)
 best = None
-for it in range(3):
+for it in range(4):
     st = KnnStats()
-    idx, sc = qc.knn_multi(qs, k, engine=KNN_MFMA, stats=st)
-    if best is None or st.total_ms < best.total_ms:
+    idx, sc = qc.knn_multi(qs, k, engine=engine, stats=st)
+    assert st.engine == engine
+    if it and (best is None or st.total_ms < best.total_ms):  # the first call builds the packed corpus copy
         best = st
-flop = 2.0 * nq * n * dim
+ops = 2.0 * nq * n * dim
 st1 = KnnStats()
 i1, s1 = qc.knn_multi(qs[:4], k, engine=KNN_EXACT, stats=st1)
 assert np.array_equal(i1, idx[:4]) and np.array_equal(s1.view(np.uint32), sc[:4].view(np.uint32))
-print(json.dumps({"workload": f"batch_knn_u8 {n}x{dim} u8, {nq} queries, k={k}", "engine": "f32 MFMA on widened u8 codes (path B)",
+peak = PEAK_I8_TOPS if which == "i8" else PEAK_F32_TFLOPS
+print(json.dumps({"workload": f"batch_knn_u8 {n}x{dim} u8, {nq} queries, k={k}",
+                  "engine": "int8 MFMA filter, 2 limbs (v_mfma_i32_32x32x32_i8) + exact f32 re-score + proof" if which == "i8"
+                            else "f32 MFMA on widened u8 codes (path B)",
                   "total_ms": best.total_ms, "gemm_ms": best.gemm_ms, "vectors_per_s": nq * n / (best.total_ms * 1e-3),
-                  "qps": nq / (best.total_ms * 1e-3), "gemm_tflops": flop / (best.gemm_ms * 1e-3) / 1e12,
-                  "frac_f32_mfma_peak": flop / (best.gemm_ms * 1e-3) / 1e12 / 157.3, "corpus_GB": n * dim / 1e9,
-                  "queries_fallback": best.queries_fallback, "candidates_kept": best.candidates_kept,
+                  "qps": nq / (best.total_ms * 1e-3),
+                  "roofline": {"bound": "mfma", "kernel": "gemm_i8_filter_kernel" if which == "i8" else "gemm_filter_kernel<kGemmU8>",
+                               "achieved": ops / (best.gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TOP/s" if which == "i8" else "TFLOP/s",
+                               "frac": ops / (best.gemm_ms * 1e-3) / 1e12 / peak, "algorithmic_ops_per_launch": ops,
+                               "executed_ops_per_launch": ops * (2 if which == "i8" else 1)},
+                  "corpus_GB": n * dim / 1e9, "queries_fallback": best.queries_fallback, "candidates_kept": best.candidates_kept,
                   "exact_engine_4q_ms": st1.total_ms, "exact_engine_GBps": n * dim / (st1.total_ms * 1e-3) / 1e9,
-                  "parity": "GEMM engine == exact engine on 4 queries (bitwise)"}))
+                  "parity": "filter engine == exact engine on 4 queries (bitwise)"}))

@@ -101,7 +101,7 @@ for name in names:
     short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3,\4>", name)
     short = re.sub(r".*gemm_bf16_filter_kernelILi(\d+)ELi(\d+)E.*", r"bf16<\1,\2>", short)
     short = re.sub(r".*gemm_i8_filter_kernelILi(\d+)ELi(\d+)E.*", r"i8<\1,\2>", short)
-    want_pairs = 16 if "gemm_i8_filter_kernel" in name else 8  # the int8 kernel carries two limbs per operand
+    want_pairs = 8  # f32: 8 k-pairs of one K-step; bf16 / int8: 2 ring positions x 2 depths x 2 fragments
     status = "ok" if (len(pairs) == want_pairs and not bad and not unsafe) else "FAIL"
     print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads, {len(unsafe)} asm loads without s_mov_b64 base  {status}")
     for b in (bad + unsafe)[:5]:

@@ -1711,12 +1711,13 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
 
 template <int QB>
 static innr_status launch_scan_u8(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, uint32_t nblocks,
-                                  uint32_t KP, uint32_t cap, uint32_t cps, uint32_t groups = 1) {
+                                  uint32_t KP, uint32_t cap, uint32_t cps, uint32_t groups = 1, size_t limit_n = 0) {
     innr_ctx* c = b->ctx;
+    const uint32_t nvalid = (uint32_t)((limit_n && limit_n < b->N) ? limit_n : b->N);
     const float a255 = b->alpha / 255.0f;  // scalar.rs:299 (params.alpha / 255.0), f32
 #define INNR_U8_LAUNCH(RR)                                                                                          \
     scan_u8_filter_kernel<QB, RR><<<dim3(nblocks, groups), 256, 0, c->stream>>>(                                    \
-        b->C8, b->ldN, (uint32_t)b->N, (uint32_t)b->D, dQ, ldq, qsum, a255, b->offset, c->lists.as<uint64_t>(),      \
+        b->C8, b->ldN, nvalid, (uint32_t)b->D, dQ, ldq, qsum, a255, b->offset, c->lists.as<uint64_t>(),              \
         c->counts.as<uint32_t>(), QB * groups, KP, cps, c->flags.as<uint32_t>())
     switch (cap) {
         case 384: INNR_U8_LAUNCH(6); break;
@@ -1729,19 +1730,21 @@ static innr_status launch_scan_u8(innr_batch* b, const float* dQ, size_t ldq, co
 }
 
 // exact engine for queries [q0, q0+nq): qsum[] precomputed on device for all queries
+// limit_n != 0: only the first limit_n documents take part (threshold seeding of the int8 engine)
 static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, size_t q0, size_t nq,
-                                      size_t kout, uint64_t* d_out_idx, float* d_out_score) {
+                                      size_t kout, uint64_t* d_out_idx, float* d_out_score, size_t limit_n = 0) {
     innr_ctx* c = b->ctx;
     const uint32_t KP = pick_kp(kout, 0);
     const uint32_t cap = exact_cap(KP);
-    const size_t nchunks = b->ldN / kU8Chunk;
+    const size_t cols = (limit_n && limit_n < b->N) ? round_up(limit_n, kU8Chunk) : b->ldN;  // columns that are scanned
+    const size_t nchunks = cols / kU8Chunk;
     size_t nslots = std::min<size_t>(nchunks, (size_t)c->num_cus * 16);
     nslots = round_up(nslots, 4);
     const uint32_t cps = (uint32_t)((nchunks + nslots - 1) / nslots);
     const uint32_t nblocks = (uint32_t)(nslots / 4);
     // a code corpus that stays in the Infinity Cache: all 4-query groups in one launch (see knn_exact_range)
     size_t max_groups = 1;
-    if (b->ldN * b->D <= (size_t)128 << 20)
+    if (cols * b->D <= (size_t)128 << 20)
         max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * 4 * cap * sizeof(uint64_t)));
     max_groups = std::min<size_t>(max_groups, 65535);
     size_t done = 0;
@@ -1767,8 +1770,8 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
             q = c->q_pad.as<float>();
             qs = qs_pad;
         }
-        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups));
-        else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps));
+        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n));
+        else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps, 1, limit_n));
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
         const uint32_t total = nreal * (uint32_t)kout;
         emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(c->sel.as<uint64_t>(), KP, nreal, (uint32_t)kout, false,
@@ -1913,13 +1916,15 @@ static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
 }
 
 template <int MODE>
-static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, const float* qc, float* dump, size_t ld_dump) {
+static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, const float* qc, float* dump, size_t ld_dump,
+                                  const uint32_t* seed = nullptr) {
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
     const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
     INNR_TRY(c->gthr.ensure(gbytes));
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
+    if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
 #define INNR_I8_LAUNCH(RR)                                                                                                  \
     gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(                                             \
         b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc,                  \
@@ -1961,16 +1966,30 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     const float* qc = c->misc.as<float>();
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 4 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
-    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
-    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(launch_gemm_i8<0>(b, p, qc, nullptr, 0));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
     const float a255 = b->alpha / 255.0f;
     // the reference's own f32 accumulation against the true sum: (D + 2) u ||q|| max||c||, ||c|| <= 255 sqrt(D) (the bound of
     // knn_u8_mfma, whose MFMA-chain half is simply unused here); the query's quantisation share comes per query (qc[3])
     const float err_scale = 1.05f * fabsf(a255) * (2.0f * (float)b->D + 12.0f) * 5.9604645e-08f * 255.0f * sqrtf((float)b->D);
+    // threshold seeding (cf. knn_mfma): the exact top-KP of a 2048-document prefix per query; their KP-th exact score
+    // lowered by the query's error bound is a valid chip-wide bound from the first tile on
+    const uint32_t* seed = nullptr;
+    constexpr size_t kSeedN = 2048;
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
+        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_u8_exact_range(b, dQ, b->D, qsum, 0, Q, p.KP, c->seed_idx.as<uint64_t>(), c->seed_score.as<float>(), kSeedN));
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
+        seed_thresholds_u8_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(
+            c->seed_score.as<float>(), (uint32_t)Q, p.KP, err_scale, qnorm, qsum, b->offset, qc + 3 * p.Qpad, sd, (uint32_t)p.Qpad);
+        INNR_HIP_CHECK(hipGetLastError());
+        seed = sd;
+    }
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY(launch_gemm_i8<0>(b, p, qc, nullptr, 0, seed));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
 #define INNR_RESCORE_U8(RKV)                                                                                          \
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \

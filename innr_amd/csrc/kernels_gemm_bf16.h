@@ -25,6 +25,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kBfStages = 8, kBfLead = 2, kBfStageBytes = 8192, kBfWaves = 8, kBfK = 32;
+static_assert(kBfStages == 8 && kBfLead == 2, "the one-barrier-per-two-steps schedule is derived for an 8-stage ring and a 2-step register ring");
 
 // round-to-nearest-even f32 -> bf16 (NaN stays NaN, quieted)
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
@@ -221,9 +222,16 @@ __global__ __launch_bounds__(64 * kBfWaves, 1) void gemm_bf16_filter_kernel(
             } else {
                 ++ks;
             }
-            // this wave's piece of step + 1 (issued kBfStages - 3 steps ago) has landed; younger ops stay in flight
-            wait_but_youngest<5 * (kBfStages - 3) + 4>();
-            __syncthreads();
+            // ONE barrier per kLead = 2 K-steps: between two barriers the block reads stages s, s + 1 and its DMAs write the
+            // stages of steps s + 6, s + 7 -- last read two steps before the previous barrier, never one of the two in use.
+            // At the barrier this wave's pieces of steps s + 2 and s + 3 must have landed: the younger one was issued at the
+            // top of step s - 3, with 4 + 5 (STAGES - 4) VMEM ops of this wave behind it (more after an epilogue: the wait
+            // is then only stricter). The waves of a SIMD drift apart inside the two-step window instead of meeting at a
+            // barrier every 16 MFMAs.
+            if (r == kBfLead - 1) {
+                wait_but_youngest<5 * (kBfStages - 4) + 4>();
+                __syncthreads();
+            }
         }
     }
     wait_all();

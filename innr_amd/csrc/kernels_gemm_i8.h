@@ -37,6 +37,7 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kI8Stages = 8, kI8Lead = 2, kI8StageBytes = 8192, kI8Waves = 8, kI8K = 64, kI8BQ = 256;
+static_assert(kI8Stages == 8 && kI8Lead == 2, "the one-barrier-per-two-steps schedule is derived for an 8-stage ring and a 2-step register ring");
 
 // largest 16-bit-fixed-point magnitude T = 256 R1 + 127 such that |V| <= D * 128 * T stays below 2^31
 __host__ __device__ inline uint32_t i8_limb_r1(uint32_t D) {
@@ -146,6 +147,23 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
         qc[2 * (size_t)Qpad + j] = 1.0f / A;
         qc[3 * (size_t)Qpad + j] = E;
     }
+}
+
+// seed[j] = the KP-th best exact score of a corpus prefix, lowered by the query's whole error bound (rescore_u8_kernel's E):
+// at least KP documents have an APPROXIMATE score above it, so it is a valid chip-wide bound. 0 = "no bound".
+__global__ void seed_thresholds_u8_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
+                                          float err_scale, const float* __restrict__ qnorm, const float* __restrict__ qsum,
+                                          float offset, const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Qpad) return;
+    uint32_t o = 0;
+    if (j < Q) {
+        const float x = kth_scores[(size_t)j * KP + KP - 1];
+        const float E = err_scale * qnorm[j] + 4.8e-7f * fabsf(offset * qsum[j]) + eq[j];
+        const float t = x - E * 1.0001f - 1e-30f;
+        if (t - t == 0.0f) o = f32_ord(t);
+    }
+    seed[j] = o;
 }
 
 template <int N> __device__ __forceinline__ void use_after1(uint32_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N)); }
@@ -258,10 +276,21 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
                 if (m == 0) use_after<kYounger>(breg[r][0], breg[r][1]);
                 else use_after<kYounger>(breg[r][2], breg[r][3]);
                 const i32x4_t bhi = __builtin_bit_cast(i32x4_t, breg[r][2 * m]), blo = __builtin_bit_cast(i32x4_t, breg[r][2 * m + 1]);
+                // A tile's first MFMAs take the constant 0 as their C operand instead of 128 zeroed accumulator registers per
+                // tile (a tile starts on ring position 0: nk is even): the epilogue leaves the registers as they are.
+                if (r == 0 && m == 0 && ks == 0) {
+                    const i32x16_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], bhi, acc[rt][0], 0, 0, 0);
-                    acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], blo, acc[rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < 4; ++rt) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], bhi, zero, 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], blo, zero, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], bhi, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], blo, acc[rt][1], 0, 0, 0);
+                    }
                 }
                 issue_b(breg[r][2 * m], breg[r][2 * m + 1], m);  // the same registers, kI8Lead steps ahead
                 __builtin_amdgcn_sched_barrier(0);
@@ -364,21 +393,22 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-                    for (int L = 0; L < 2; ++L)
-#pragma unroll
-                        for (int g = 0; g < 16; ++g) acc[rt][L][g] = 0;
                 if (MODE == 0) gload1_agent(tg_next, gthr + q0 + 32 * wu, 4u * (uint32_t)C);
                 ks = 0;
                 ++tile;
             } else {
                 ++ks;
             }
-            // this wave's piece of step + 1 (issued kI8Stages - 3 steps ago) has landed; younger ops stay in flight
-            wait_but_youngest<5 * (kI8Stages - 3) + 4>();
-            __syncthreads();
+            // ONE barrier per kLead = 2 K-steps: between two barriers the block reads stages s, s + 1 and its DMAs write the
+            // stages of steps s + 6, s + 7 -- last read two steps before the previous barrier, never one of the two in use.
+            // At the barrier this wave's pieces of steps s + 2 and s + 3 must have landed: the younger one was issued at the
+            // top of step s - 3, with 4 + 5 (STAGES - 4) VMEM ops of this wave behind it (more after an epilogue: the wait
+            // is then only stricter). The waves of a SIMD drift apart inside the two-step window instead of meeting at a
+            // barrier every 16 MFMAs.
+            if (r == kI8Lead - 1) {
+                wait_but_youngest<5 * (kI8Stages - 4) + 4>();
+                __syncthreads();
+            }
         }
     }
     wait_all();

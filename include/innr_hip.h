@@ -150,6 +150,10 @@ innr_status innr_batch_generate_u8(innr_ctx* ctx, size_t N, size_t D, uint64_t s
                                    float offset, innr_batch** out);
 /* codes back to the host, dimension-major out[d*N + i] */
 innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out);
+/* ... and in again from that order (persistence: a saved code corpus is its data[d*N + i] behind a small header, like
+ * VerticalBatch::data() for the f32 store, batch.rs:208-214) */
+innr_status innr_batch_upload_u8_colmajor(innr_ctx* ctx, const uint8_t* data, size_t N, size_t D, float alpha, float offset,
+                                          innr_batch** out);
 /* asymmetric_dot_u8_precomputed for every document (scalar.rs:284-300; the map inside batch_knn_u8 :384-388):
  * out[i] = (alpha/255)*mixed_dot(q, codes_i) + offset*sum(q), bit-identical to the portable path. */
 innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float* out);
@@ -172,6 +176,11 @@ innr_status innr_batch_quantize_u8(innr_batch* f32_batch, float alpha, float off
  * *out_any = 0 when the batch holds no non-NaN value (the reference then returns alpha 1, offset 0). The order of
  * the reference's sequential scan decides between -0.0 and +0.0; here -0.0 < +0.0. */
 innr_status innr_batch_minmax(innr_batch* f32_batch, float* out_min, float* out_max, int* out_any);
+/* QuantizationParams::fit_quantile's range (scalar.rs:104-139) of a resident f32 batch: the values at the reference's two
+ * ranks (its own f32 index arithmetic, :131-134) of the FINITE values sorted by total_cmp, found by a radix select on the
+ * device (five corpus streams, no sort). quantile >= 1: the plain min/max of fit() (:118-120). *out_any = 0: no finite value
+ * (alpha 1, offset 0). quantile outside (0, 1] is the reference's panic: INNR_E_DIM_MISMATCH with that message. */
+innr_status innr_batch_quantile_range(innr_batch* f32_batch, float quantile, float* out_lo, float* out_hi, int* out_any);
 
 /* ---- maxsim over a document corpus (src/maxsim.rs:96-194; caller shape examples/maxsim_colbert.rs:159-193) ---- */
 typedef struct innr_docs innr_docs; /* device-resident token embeddings of `docs` documents, T tokens x dim each */
@@ -184,6 +193,9 @@ innr_status innr_maxsim_generate(innr_ctx* ctx, size_t docs, size_t T, size_t di
                                  innr_docs** out);
 void innr_docs_free(innr_docs* d);
 size_t innr_docs_count(const innr_docs* d);
+/* persistence of a document corpus: its shape, and its tokens [docs*T*dim] (+ doc_len[docs] when it has them; may be NULL) */
+innr_status innr_docs_shape(const innr_docs* d, size_t* ndocs, size_t* T, size_t* dim, int* has_doc_len);
+innr_status innr_docs_download(innr_docs* d, float* tokens, uint32_t* doc_len);
 innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base);
 /* maxsim(query, doc_i) (cosine == 0) or maxsim_cosine (cosine != 0) for EVERY document: out[docs], bit-identical
  * to the portable path (dot_portable / cosine_portable order). qtok: [Tq*dim]. Empty query/document -> 0.0. */

@@ -119,6 +119,10 @@ SIGNATURES = {
     "innr_hamming_u8": (C.c_uint32, [_vp, _vp, _sz]),
     "innr_slot_distance_u32": (C.c_float, [_vp, _vp, _sz]),
     "innr_maxsim_pair": (C.c_int, [_vp, _sz, _vp, _sz, _sz, C.c_int, _f32p]),
+    "innr_batch_quantile_range": (C.c_int, [_vp, C.c_float, _f32p, _f32p, C.POINTER(C.c_int)]),
+    "innr_batch_upload_u8_colmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.c_float, C.c_float, C.POINTER(_vp)]),
+    "innr_docs_shape": (C.c_int, [_vp, _szp, _szp, _szp, C.POINTER(C.c_int)]),
+    "innr_docs_download": (C.c_int, [_vp, _vp, _vp]),
     "innr_comm_unique_id": (C.c_int, [_vp]),
     "innr_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "innr_comm_attach": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),

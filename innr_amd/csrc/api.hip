@@ -319,6 +319,7 @@ static uint32_t exact_cap(uint32_t KP) { return KP <= 32 ? 384u : (KP <= 128 ? 7
 struct ScanExt {
     const uint8_t* mask = nullptr;    // [ldN] predicate bytes (batch_knn_filtered)
     const uint32_t* order = nullptr;  // [D] dimension order (batch_knn_reordered)
+    uint32_t nvalid = 0xFFFFFFFFu;    // query slots of the launch beyond this one are padding (zero rows): nothing is admitted for them
 };
 
 template <int QB, int R>
@@ -333,20 +334,20 @@ static innr_status launch_scan_filter_r(innr_batch* b, int metric, const float* 
     switch (metric) {
         case INNR_METRIC_DOT:
             scan_filter_kernel<QB, false, false, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
+                b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err, nullptr, nullptr, ext.nvalid);
             break;
         case INNR_METRIC_L2SQ:
             if (ext.mask || ext.order)
                 scan_filter_kernel<QB, true, false, R, true><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
                     b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err, ext.mask,
-                    ext.order);
+                    ext.order, ext.nvalid);
             else
                 scan_filter_kernel<QB, true, false, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
-                    b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err);
+                    b->V, b->ldN, N, D, dQ, ldq, nullptr, nullptr, lists, counts, qstride, KP, cps, err, nullptr, nullptr, ext.nvalid);
             break;
         default:
             scan_filter_kernel<QB, false, true, R><<<dim3(nblocks, groups), kScanThreads, 0, c->stream>>>(
-                b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cps, err);
+                b->V, b->ldN, N, D, dQ, ldq, b->norms, dQn, lists, counts, qstride, KP, cps, err, nullptr, nullptr, ext.nvalid);
             break;
     }
     INNR_HIP_CHECK(hipGetLastError());
@@ -430,10 +431,12 @@ static innr_status knn_exact_range(innr_batch* b_full, int metric, const float* 
             }
             q = c->q_pad.as<float>();
         }
+        ScanExt ext2 = ext;
+        if (nreal < nql) ext2.nvalid = nreal;
         switch (qb) {
-            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext, groups)); break;
-            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
-            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext)); break;
+            case 8: INNR_TRY(launch_scan_filter<8>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext2, groups)); break;
+            case 4: INNR_TRY(launch_scan_filter<4>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext2)); break;
+            default: INNR_TRY(launch_scan_filter<1>(b, metric, q, ldq, qn, nblocks, nql, KP, cap, cps, ext2)); break;
         }
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
         const uint32_t total = nreal * (uint32_t)kout;
@@ -447,6 +450,14 @@ static innr_status knn_exact_range(innr_batch* b_full, int metric, const float* 
 }
 
 // ---- GEMM engine -------------------------------------------------------------------------------------
+// The query tile of a GEMM-type engine is padded with zero queries. Left alone they cost MORE than real ones: every score
+// is 0, every vector ties, every tile appends and compacts (a 16-query batch on a 256-query tile took 100 ms at C2 where 256
+// real queries take 28). Their chip-wide bound starts at the largest key instead: nothing is ever admitted for them.
+static innr_status close_padding_queries(innr_ctx* c, uint32_t* gthr, size_t nreal_q, size_t Qpad) {
+    if (nreal_q < Qpad) INNR_HIP_CHECK(hipMemsetAsync(gthr + nreal_q, 0xFF, (Qpad - nreal_q) * sizeof(uint32_t), c->stream));
+    return INNR_OK;
+}
+
 struct GemmPlan {
     size_t Qpad;
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, waves;
@@ -460,7 +471,14 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
     // 107.9 ms, L2 107.7 vs 108.3, u8 at C3 571 vs 582 (its 2 KiB corpus stage is only two DMA pieces, which eight
     // waves issue four times over).
     p.waves = (Q > 256 && dot_kind && !b->C8) ? 8u : 4u;
-    if (const char* e = getenv("INNR_GEMM_WAVES")) p.waves = atoi(e) == 8 ? 8u : 4u;
+    // Small query batches: 64- and 128-query tiles (1- and 2-wave blocks, several per CU) instead of padding a 256-query
+    // tile -- at 64 queries the f32 MFMA time (6.2 ms at C2) and the corpus stream (5.2 ms) are balanced.
+    if (!b->C8 && Q <= 64) p.waves = 1u;
+    else if (!b->C8 && Q <= 128) p.waves = 2u;
+    if (const char* e = getenv("INNR_GEMM_WAVES")) {
+        const int w = atoi(e);
+        if (w == 8 || w == 4 || ((w == 2 || w == 1) && !b->C8)) p.waves = (uint32_t)w;
+    }
     if (force_waves) p.waves = force_waves;
     const size_t bq = 64 * p.waves;
     p.Qpad = round_up(Q, bq);
@@ -468,7 +486,10 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
     p.KP = pick_kp(kout, 16);
     p.cap = (uint32_t)cand_cap((int)p.KP);
     const uint32_t ntiles = (uint32_t)(b->ldN / kBC);
-    uint32_t target = (uint32_t)((8 / p.waves) * b->ctx->num_cus) / p.nqt;  // resident blocks per CU: 8 waves' worth
+    // resident blocks per CU: 8 waves' worth by registers, but never more blocks than SIMDs
+    uint32_t per_cu = std::min(8u / p.waves, 4u);  // 1-wave blocks: one per SIMD (measured 4 / 5 / 6 per CU: 9.96 / 13.6 / 11.8 ms at Q = 64, C2)
+    if (const char* e = getenv("INNR_GEMM_BLOCKS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(atoi(e), 8));
+    uint32_t target = (uint32_t)(per_cu * b->ctx->num_cus) / p.nqt;
     uint32_t ns = std::max(8u, target / 8 * 8);
     ns = std::min(ns, (uint32_t)round_up(ntiles, 8));
     p.nslices = ns;
@@ -491,7 +512,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
 }
 
 template <int KIND, int MODE>
-static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt, const float* invn, const float* invq,
+static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, size_t nreal_q, const float* Qt, const float* invn, const float* invq,
                                float* dump, size_t ld_dump, const uint32_t* seed = nullptr) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
@@ -505,15 +526,19 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, const float* Qt
     uint32_t* gslots = c->gthr.as<uint32_t>();
     if (seed)  // initial chip-wide bounds (see seed_thresholds_kernel): valid lower bounds, the slots start empty as usual
         INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
 #define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
     gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
         p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + nslot, dump,   \
         ld_dump)
-    // the 8-wave (512-query) tile exists for the product path only (MODE 0); the layout-dump hook stays on 4 waves
+    // the 8-, 2- and 1-wave tiles exist for the product path only (MODE 0; the narrow ones not for the u8 kind); the
+    // layout-dump hook stays on 4 waves
 #define INNR_GEMM_LAUNCH(RR)                                                                                    \
     do {                                                                                                        \
         if (MODE == 0 && p.waves == 8) INNR_GEMM_LAUNCH_W(RR, (MODE == 0 ? 8 : 4));                              \
+        else if (MODE == 0 && KIND != kGemmU8 && p.waves == 2) INNR_GEMM_LAUNCH_W(RR, ((MODE == 0 && KIND != kGemmU8) ? 2 : 4)); \
+        else if (MODE == 0 && KIND != kGemmU8 && p.waves == 1) INNR_GEMM_LAUNCH_W(RR, ((MODE == 0 && KIND != kGemmU8) ? 1 : 4)); \
         else INNR_GEMM_LAUNCH_W(RR, 4);                                                                         \
     } while (0)
     switch (p.cap) {
@@ -659,7 +684,7 @@ static innr_status ensure_bf16_corpus(innr_batch* b) {
     return INNR_OK;
 }
 
-static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, const uint32_t* seed) {
+static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed) {
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
     const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
@@ -667,6 +692,7 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, const uint
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
     if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
 #define INNR_BF16_LAUNCH(RR)                                                                                              \
     gemm_bf16_filter_kernel<RR, 0><<<p.nblocks, 64 * kBfWaves, 0, c->stream>>>(                                             \
         b->Ab, c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps,      \
@@ -760,12 +786,12 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     }
 
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
-    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
-    else if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, seed));
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
+    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, Q, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
+    else if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed));
     // (A first pass of the same kernel over 1/16 of the corpus, only to harvest tighter bounds for the full pass, was
     //  tried: 17.6 ms for both against 16.4 for the single pass.)
-    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
+    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
@@ -1076,9 +1102,9 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
-    if (cos) INNR_TRY((launch_gemm<kGemmCos, 1>(b, p, c->q_kmajor.as<float>(), b->invn, c->misc.as<float>(),
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 1>(b, p, Q, c->q_kmajor.as<float>(), b->invn, c->misc.as<float>(),
                                             c->scores.as<float>(), b->ldN)));
-    else INNR_TRY((launch_gemm<kGemmDot, 1>(b, p, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
+    else INNR_TRY((launch_gemm<kGemmDot, 1>(b, p, Q, c->q_kmajor.as<float>(), nullptr, nullptr, c->scores.as<float>(), b->ldN)));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float),
                                     b->N * sizeof(float), Q, hipMemcpyDeviceToHost, c->stream));
     INNR_HIP_CHECK(ctx_sync(c));
@@ -1236,7 +1262,9 @@ static bool gemm_addressable(const innr_batch* b, size_t Q) {
 
 int innr_batch_auto_engine(const innr_batch* b, size_t Q) {
     if (!b) return INNR_KNN_EXACT;
-    return (Q >= 16 && b->N >= 65536 && gemm_addressable(b, Q)) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
+    // from 9 queries on, the GEMM engine's 64-query tile (9-10 ms at 10M x 768) beats two passes of the exact engine (6.6 + 5.5 ms);
+    // up to 8 queries one exact pass is faster (profiles/r02_midq_10Mx768.txt)
+    return (Q >= 9 && b->N >= 65536 && gemm_addressable(b, Q)) ? INNR_KNN_MFMA : INNR_KNN_EXACT;
 }
 
 size_t innr_batch_num_vectors(const innr_batch* b) { return b ? b->N : 0; }
@@ -1664,6 +1692,90 @@ innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int
     return INNR_OK;
 }
 
+// QuantizationParams::fit_quantile's range (scalar.rs:104-139) of a resident f32 batch, without sorting it: the finite values'
+// count M from a first histogram pass, the reference's two ranks from M in its own f32 arithmetic (:131-134), then a 4-pass
+// radix select (one byte of the total_cmp key per pass, both ranks per pass) -- five streams of the corpus instead of a sort.
+innr_status innr_batch_quantile_range(innr_batch* b, float quantile, float* out_lo, float* out_hi, int* out_any) {
+    if (!b || !b->V || !out_lo || !out_hi || !out_any) {
+        set_error("innr_batch_quantile_range needs an f32 batch");
+        return INNR_E_BAD_ARG;
+    }
+    if (!(quantile > 0.0f && quantile <= 1.0f)) {  // assert!(quantile > 0.0 && quantile <= 1.0), scalar.rs:106-109
+        set_error("quantile must be in (0.0, 1.0]");
+        return INNR_E_DIM_MISMATCH;  // the reference panics: the host shims turn this status into their panic
+    }
+    if (quantile >= 1.0f) return innr_batch_minmax(b, out_lo, out_hi, out_any);  // scalar.rs:118-120: fit()
+    innr_ctx* c = b->ctx;
+    INNR_ENTER(c);
+    *out_any = 0;
+    *out_lo = 0.0f;
+    *out_hi = 0.0f;
+    if (b->N == 0 || b->D == 0) return INNR_OK;
+    INNR_TRY(c->misc.ensure(512 * sizeof(unsigned long long)));
+    unsigned long long* dh = c->misc.as<unsigned long long>();
+    dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+    unsigned long long hist[512];
+    uint32_t pref[2] = {0u, 0u};
+    unsigned long long rank[2] = {0ull, 0ull};
+    for (int pass = 0; pass < 4; ++pass) {
+        const uint32_t shift = 24 - 8 * pass, himask = pass ? (0xFFFFFFFFu << (shift + 8)) : 0u;
+        INNR_HIP_CHECK(hipMemsetAsync(dh, 0, sizeof(hist), c->stream));
+        quantile_hist_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, shift, himask, pref[0], pref[1], dh);
+        INNR_HIP_CHECK(hipGetLastError());
+        INNR_HIP_CHECK(hipMemcpyAsync(hist, dh, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (pass == 0) {
+            unsigned long long M = 0;
+            for (int i = 0; i < 256; ++i) M += hist[i];
+            if (M == 0) return INNR_OK;  // no finite value: alpha 1, offset 0 (scalar.rs:124-129)
+            const float tail = (1.0f - quantile) / 2.0f;  // scalar.rs:131-134, f32 arithmetic
+            unsigned long long lo = (unsigned long long)floorf(tail * (float)M);
+            unsigned long long hi = (unsigned long long)ceilf((1.0f - tail) * (float)M);
+            if (hi > M - 1) hi = M - 1;
+            if (lo > M - 1) lo = M - 1;  // (the reference would index out of bounds; cannot happen for quantile in (0, 1))
+            rank[0] = lo;
+            rank[1] = hi;
+        }
+        for (int w = 0; w < 2; ++w) {  // the digit whose bucket holds the rank; the rank becomes relative to that bucket
+            unsigned long long acc = 0;
+            int dig = 255;
+            for (int i = 0; i < 256; ++i) {
+                if (rank[w] < acc + hist[256 * w + i]) {
+                    dig = i;
+                    break;
+                }
+                acc += hist[256 * w + i];
+            }
+            rank[w] -= acc;
+            pref[w] |= (uint32_t)dig << shift;
+        }
+    }
+    *out_lo = ord_f32(pref[0]);
+    *out_hi = ord_f32(pref[1]);
+    *out_any = 1;
+    return INNR_OK;
+}
+
+// codes already dimension-major (what innr_batch_download_u8 wrote / a saved corpus holds): data[d*N + i]
+innr_status innr_batch_upload_u8_colmajor(innr_ctx* ctx, const uint8_t* data, size_t N, size_t D, float alpha, float offset,
+                                          innr_batch** out) {
+    if ((!data && N * D) || !ctx) return INNR_E_BAD_ARG;
+    INNR_ENTER(ctx);
+    innr_batch* b = nullptr;
+    INNR_TRY(alloc_batch_u8(ctx, N, D, alpha, offset, &b));
+    if (N && D) {
+        hipError_t e = hipMemcpy2DAsync(b->C8, b->ldN, data, N, N, D, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = ctx_sync(ctx);
+        if (e != hipSuccess) {
+            set_error("u8 corpus upload failed: %s", hipGetErrorString(e));
+            innr_batch_free(b);
+            return INNR_E_HIP;
+        }
+    }
+    *out = b;
+    return INNR_OK;
+}
+
 innr_status innr_batch_download_u8(innr_batch* b, uint8_t* out) {
     if (!b || !b->C8 || (!out && b->N * b->D)) return INNR_E_BAD_ARG;
     if (b->N == 0 || b->D == 0) return INNR_OK;
@@ -1711,14 +1823,15 @@ innr_status innr_batch_scores_u8(innr_batch* b, const float* q, size_t D, float*
 
 template <int QB>
 static innr_status launch_scan_u8(innr_batch* b, const float* dQ, size_t ldq, const float* qsum, uint32_t nblocks,
-                                  uint32_t KP, uint32_t cap, uint32_t cps, uint32_t groups = 1, size_t limit_n = 0) {
+                                  uint32_t KP, uint32_t cap, uint32_t cps, uint32_t groups = 1, size_t limit_n = 0,
+                                  uint32_t nvalid_q = 0xFFFFFFFFu) {
     innr_ctx* c = b->ctx;
     const uint32_t nvalid = (uint32_t)((limit_n && limit_n < b->N) ? limit_n : b->N);
     const float a255 = b->alpha / 255.0f;  // scalar.rs:299 (params.alpha / 255.0), f32
 #define INNR_U8_LAUNCH(RR)                                                                                          \
     scan_u8_filter_kernel<QB, RR><<<dim3(nblocks, groups), 256, 0, c->stream>>>(                                    \
         b->C8, b->ldN, nvalid, (uint32_t)b->D, dQ, ldq, qsum, a255, b->offset, c->lists.as<uint64_t>(),              \
-        c->counts.as<uint32_t>(), QB * groups, KP, cps, c->flags.as<uint32_t>())
+        c->counts.as<uint32_t>(), QB * groups, KP, cps, c->flags.as<uint32_t>(), nvalid_q)
     switch (cap) {
         case 384: INNR_U8_LAUNCH(6); break;
         case 768: INNR_U8_LAUNCH(12); break;
@@ -1770,7 +1883,7 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
             q = c->q_pad.as<float>();
             qs = qs_pad;
         }
-        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n));
+        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n, nreal < nql ? nreal : 0xFFFFFFFFu));
         else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps, 1, limit_n));
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
         const uint32_t total = nreal * (uint32_t)kout;
@@ -1833,7 +1946,7 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY((launch_gemm<kGemmU8, 0>(b, p, c->q_kmajor.as<float>(), nullptr, oq, nullptr, 0)));
+    INNR_TRY((launch_gemm<kGemmU8, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, oq, nullptr, 0)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
                         (uint32_t)Q));
@@ -1916,7 +2029,7 @@ static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
 }
 
 template <int MODE>
-static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, const float* qc, float* dump, size_t ld_dump,
+static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q, const float* qc, float* dump, size_t ld_dump,
                                   const uint32_t* seed = nullptr) {
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
@@ -1925,6 +2038,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, const float* q
     INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
     uint32_t* gslots = c->gthr.as<uint32_t>();
     if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
 #define INNR_I8_LAUNCH(RR)                                                                                                  \
     gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(                                             \
         b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc,                  \
@@ -1987,7 +2101,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(launch_gemm_i8<0>(b, p, qc, nullptr, 0, seed));
+    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
 #define INNR_RESCORE_U8(RKV)                                                                                          \
@@ -2031,7 +2145,7 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
-    INNR_TRY(launch_gemm_i8<1>(b, p, c->misc.as<float>(), c->scores.as<float>(), b->ldN));
+    INNR_TRY(launch_gemm_i8<1>(b, p, Q, c->misc.as<float>(), c->scores.as<float>(), b->ldN));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float), b->N * sizeof(float), Q,
                                     hipMemcpyDeviceToHost, c->stream));
     if (qc_out) INNR_HIP_CHECK(hipMemcpyAsync(qc_out, c->misc.p, 4 * p.Qpad * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -2209,6 +2323,27 @@ void innr_docs_free(innr_docs* d) {
 }
 
 size_t innr_docs_count(const innr_docs* d) { return d ? d->ndocs : 0; }
+
+innr_status innr_docs_shape(const innr_docs* d, size_t* ndocs, size_t* T, size_t* dim, int* has_doc_len) {
+    if (!d) return INNR_E_BAD_ARG;
+    if (ndocs) *ndocs = d->ndocs;
+    if (T) *T = d->T;
+    if (dim) *dim = d->dim;
+    if (has_doc_len) *has_doc_len = d->doc_len ? 1 : 0;
+    return INNR_OK;
+}
+
+// tokens[docs*T*dim] (the layout innr_maxsim_upload takes) and, when the corpus has them, doc_len[docs]
+innr_status innr_docs_download(innr_docs* d, float* tokens, uint32_t* doc_len) {
+    if (!d || (!tokens && d->ndocs * d->T * d->dim)) return INNR_E_BAD_ARG;
+    INNR_ENTER(d->ctx);
+    const size_t n = d->ndocs * d->T * d->dim;
+    if (n) INNR_HIP_CHECK(hipMemcpyAsync(tokens, d->tok, n * sizeof(float), hipMemcpyDeviceToHost, d->ctx->stream));
+    if (doc_len && d->doc_len && d->ndocs)
+        INNR_HIP_CHECK(hipMemcpyAsync(doc_len, d->doc_len, d->ndocs * sizeof(uint32_t), hipMemcpyDeviceToHost, d->ctx->stream));
+    INNR_HIP_CHECK(ctx_sync(d->ctx));
+    return INNR_OK;
+}
 
 innr_status innr_docs_set_index_base(innr_docs* d, uint64_t base) {
     if (!d) return INNR_E_BAD_ARG;

@@ -141,8 +141,11 @@ enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 //                ds_read_b32 feeds the four row tiles) and score = scale * (q.c) + invq[j]   (invq = offset*sum(q)):
 //                "path B" of SURVEY.md -- the f32 MFMA pipe, a quarter of the corpus bytes.
 // MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
+// WAVES: 8 = 512-query tile, one block per CU; 4 = 256 queries, two blocks per CU; 2 / 1 = 128 / 64 queries for small query
+// batches (a 64-query batch on a 256-query tile spends three quarters of its MFMAs on padding: 27 ms instead of ~8 at C2),
+// several blocks per CU, each streaming its own corpus slice (not for the u8 kind, whose small batches take the int8 engine).
 template <int KIND, int R, int MODE, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
+__global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
@@ -150,7 +153,11 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
-    constexpr int kEpiTgWait = 10;  // gemm_epilogue.inc: at most 10 VMEM ops of this wave are in flight at a tile end
+    static_assert(WAVES == 1 || WAVES == 2 || WAVES == 4 || WAVES == 8, "block = 1, 2, 4 or 8 waves");
+    static_assert(!(KIND == kGemmU8 && WAVES < 4), "the u8 kind stages two 1-KiB pieces per K-step: 4 or 8 waves");
+    // corpus DMA pieces (1 KiB = two dimension rows of the 16 x 128 stage) this wave issues per K-step
+    constexpr int NP = (KIND == kGemmU8) ? 1 : 8 / WAVES;
+    constexpr int kEpiTgWait = 8 + NP;  // gemm_epilogue.inc: at most this many VMEM ops of the wave are in flight at a tile end
     const float* V = static_cast<const float*>(Vraw);
     const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
     constexpr int kGemmWaves = WAVES, kBQ = 64 * WAVES;
@@ -188,25 +195,20 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     // Source addresses of this wave's corpus DMA pieces and query operands: a wave-uniform base, advanced on the scalar
     // unit, plus a constant per-lane byte offset (< 4 GiB: the host keeps ldN below 2^29 for this engine).
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const char* sa[2];  // bases of the 2 corpus pieces (u8 and 8-wave tiles: sa[0] only)
-    uint32_t la[2];     // stage-0 LDS destinations; stage k adds k * kStageBytesA
+    const char* sa;     // base of this wave's first corpus piece; piece j adds j * piece_step (f32: two dimension rows)
+    uint32_t la;        // its stage-0 LDS destination; piece j adds j KiB, stage k adds k * kStageBytesA
     uint32_t va;        // per-lane offset inside a piece
     // u8 corpus: the 16 x 128-byte stage is two 1-KiB pieces (8 rows each): piece (w & 1) from every wave
     if (U8) va = (uint32_t)(lane >> 3) * (uint32_t)ldN + (uint32_t)(lane & 7) * 16u;
     else va = ((uint32_t)(lane >> 5) * (uint32_t)ldN + (uint32_t)(lane & 31) * 4u) * 4u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if (U8) {
-            sa[j] = reinterpret_cast<const char*>(C8 + (size_t)(8 * (wu & 1)) * ldN + (size_t)t0 * kBC);
-            la[j] = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (wu & 1));
-        } else if (kGemmWaves == 8) {  // 8 pieces of 2 rows, one per wave
-            sa[j] = reinterpret_cast<const char*>(V + (size_t)(2 * wu) * ldN + (size_t)t0 * kBC);
-            la[j] = lds_addr_uniform(&s.A[0][2 * wu][0]);
-        } else {
-            sa[j] = reinterpret_cast<const char*>(V + (size_t)(4 * wu + 2 * j) * ldN + (size_t)t0 * kBC);
-            la[j] = lds_addr_uniform(&s.A[0][4 * wu + 2 * j][0]);
-        }
+    if (U8) {
+        sa = reinterpret_cast<const char*>(C8 + (size_t)(8 * (wu & 1)) * ldN + (size_t)t0 * kBC);
+        la = lds_addr_uniform(reinterpret_cast<const uint8_t*>(&s.A[0][0][0]) + 1024 * (wu & 1));
+    } else {  // 8 pieces of 2 rows: NP consecutive ones per wave
+        sa = reinterpret_cast<const char*>(V + (size_t)(2 * NP * wu) * ldN + (size_t)t0 * kBC);
+        la = lds_addr_uniform(&s.A[0][2 * NP * wu][0]);
     }
+    const size_t piece_step = (size_t)2 * ldN * 4;
     // B operands: k-pair kp of the K-step the base refers to sits at sb + kp * b_kp
     const char* sb = reinterpret_cast<const char*>(Qt + q0 + 64 * wu);
     const uint32_t vb = ((uint32_t)(lane >> 5) * (uint32_t)Qpad + 2u * (uint32_t)(lane & 31)) * 4u;
@@ -216,8 +218,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     // subtract at a tile change: back to row 0, next tile
 #ifdef INNR_GEMM_PROBE_L2HOT  // tools/gemm_probe.hip: every block re-reads corpus tile 0 (L2-resident operands)
     const size_t a_wrap = (size_t)(Dpad - kBK) * ldN * (U8 ? 1 : 4);
-    sa[0] -= (size_t)t0 * kBC * (U8 ? 1 : 4);
-    sa[1] -= (size_t)t0 * kBC * (U8 ? 1 : 4);
+    sa -= (size_t)t0 * kBC * (U8 ? 1 : 4);
 #else
     const size_t a_wrap = ((size_t)(Dpad - kBK) * ldN - kBC) * (U8 ? 1 : 4);
 #endif
@@ -226,11 +227,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
     auto advance = [&]() {
         if (++pks == nk) {
             pks = 0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) sa[j] -= a_wrap;
+            sa -= a_wrap;
         } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) sa[j] += a_step;
+            sa += a_step;
         }
     };
     auto advance_b = [&]() {
@@ -241,13 +240,18 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
             sb += q_step;
         }
     };
-    auto issue_a = [&](uint32_t stage_off) {
-        if (U8 || kGemmWaves == 8) {
-            glds16(sa[0], va, la[0] + stage_off);  // waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
-        } else {
-            glds16(sa[0], va, la[0] + stage_off);
-            glds16(sa[1], va, la[1] + stage_off);
-        }
+    auto issue_a = [&](uint32_t stage_off) {  // u8: waves 2-3 repeat the pieces of waves 0-1: every wave's op count is the same
+#pragma unroll
+        for (int j = 0; j < NP; ++j) glds16(sa + j * piece_step, va, la + 1024u * j + stage_off);
+    };
+    // 1- and 2-wave blocks issue 8 / 4 pieces per K-step: spread over the four MFMA groups of the step (NP / 4 behind each
+    // group's query loads) instead of in front of them, where one wave per SIMD would leave the matrix pipe idle for the
+    // ~1000 cycles the eight issues take. The waits do not move: a group's operands still have 6 + NP younger ops (NP = sum of
+    // the pieces, wherever they sit in the step), the end-of-step wait still leaves the step's own 8 + NP ops in flight.
+    constexpr bool kSpreadDma = NP >= 4;
+    auto issue_a_part = [&](uint32_t stage_off, int grp) {
+#pragma unroll
+        for (int j = grp * (NP / 4); j < (grp + 1) * (NP / 4); ++j) glds16(sa + j * piece_step, va, la + 1024u * j + stage_off);
     };
     // prologue: corpus K-steps 0 and 1 into stages 0 and 1, query operands of K-step 0 into registers
     // (pa always refers to the last K-step issued: advance, then issue -- so a pointer never leaves the slice)
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
         // the corpus DMA of step s+2 goes out first: every later wait of this step then sees it among the younger ops
 #ifndef INNR_GEMM_PROBE_NODMA_A  // tools/gemm_probe.hip
         if (has_next) advance();
-        issue_a(da);
+        if (!kSpreadDma) issue_a(da);
 #endif
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
@@ -323,8 +327,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
             // they re-fetch the last step / wrap, into a stage and registers nobody reads), so the ops younger than
             // this group's operands (loaded one step ago, after the same group) are always 6 query loads + the corpus
             // DMA (f32: 2 ops, u8: 1). One unconditional wait: a branch here made hipcc copy the registers BEFORE it.
-            if (U8 || kGemmWaves == 8) use_after<7>(breg[2 * grp], breg[2 * grp + 1]);
-            else use_after<8>(breg[2 * grp], breg[2 * grp + 1]);
+            use_after<6 + NP>(breg[2 * grp], breg[2 * grp + 1]);
             const float2 bv[2] = {breg[2 * grp], breg[2 * grp + 1]};
             if (U8) {
 #pragma unroll
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
             gload2(breg[2 * grp], sb + (2 * grp) * b_kp, vb);
             gload2(breg[2 * grp + 1], sb + (2 * grp + 1) * b_kp, vb);
 #endif
+            if (kSpreadDma) issue_a_part(da, grp);
             __builtin_amdgcn_sched_barrier(0);
         }
         advance_b();
@@ -369,8 +373,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void gemm_filter_kernel(
         }
         // This wave's corpus pieces of K-step s+1 (issued one step ago) are in LDS; the youngest ops -- the corpus
         // pieces of s+2 and the 8 query loads of s+1 -- stay in flight.
-        if (U8 || kGemmWaves == 8) wait_but_youngest<9>();
-        else wait_but_youngest<10>();
+        wait_but_youngest<8 + NP>();
 #ifndef INNR_GEMM_PROBE_NOBAR  // tools/gemm_probe.hip
         __syncthreads();  // ... so are everyone else's, and the stage just consumed may be overwritten next step
 #endif

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
                     const float thr_f = ord_f32(thr);
                     if (thr != 0u) {
                         const float x = (thr_f - Bj) * invAj;
-                        if (x >= 2.0e9f) Tint = INT32_MAX;
+                        if (x >= 2.0e9f || thr == 0xFFFFFFFFu) Tint = INT32_MAX;  // (all ones: a padding query, closed by the host)
                         else if (x > -2.0e9f) Tint = (int32_t)__builtin_floorf(x) - 2 - (int32_t)(fabsf(x) * 4.8e-7f);
                         // x <= -2e9 or NaN: everything passes
                     }

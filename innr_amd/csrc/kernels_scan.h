@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
     const float* __restrict__ norms, const float* __restrict__ qnorm, uint64_t* __restrict__ lists,
     uint32_t* __restrict__ counts, uint32_t qstride, uint32_t KP, uint32_t chunks_per_slot,
     uint32_t* __restrict__ errflag, const uint8_t* __restrict__ mask = nullptr,
-    const uint32_t* __restrict__ order = nullptr) {
+    const uint32_t* __restrict__ order = nullptr, uint32_t nvalid = 0xFFFFFFFFu) {
     constexpr uint32_t cap = 64 * R;
     __shared__ uint32_t s_cnt[kScanThreads / 64][QB];
     __shared__ uint32_t s_thr[kScanThreads / 64][QB];
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_filter_kernel(
                 float s = acc[j][c];
                 if (COS) s = cosine_epilogue(s, qn, vn[c]);
                 const uint32_t pref = score_pref<L2>(s);
-                if (i < N && pref >= thr && ((pass4 >> (8 * c)) & 0xffu))
+                // qoff + j >= nvalid: a zero row padding a ragged query tail (knn_exact_range) -- its scores all tie, nothing is kept
+                if (i < N && pref >= thr && ((pass4 >> (8 * c)) & 0xffu) && qoff + j < nvalid)
                     cand_append(my_lists + (size_t)j * cap, &s_cnt[w][j], cap, cand_make(pref, (uint32_t)i), errflag);
             }
         }

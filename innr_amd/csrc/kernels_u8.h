@@ -116,6 +116,35 @@ __global__ __launch_bounds__(256) void minmax_pdx_kernel(const float* __restrict
     }
 }
 
+// One pass of the radix select behind QuantizationParams::fit_quantile (scalar.rs:104-139: sort the FINITE values by
+// total_cmp, take the values at two ranks): digit histograms of the keys f32_ord(x) whose higher digits equal prefA / prefB
+// (himask selects those digits; pass 0: himask = 0). hist[0][256] for the low rank, hist[1][256] for the high one.
+__global__ __launch_bounds__(256) void quantile_hist_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
+                                                             uint32_t shift, uint32_t himask, uint32_t prefA, uint32_t prefB,
+                                                             unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t h[2][256];
+    h[0][threadIdx.x] = 0;
+    h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 < ldN) {
+        for (uint32_t d = blockIdx.y; d < D; d += gridDim.y) {
+            const float4 v = *reinterpret_cast<const float4*>(V + (size_t)d * ldN + i4);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (i4 + c < N && x[c] - x[c] == 0.0f) {  // is_finite
+                    const uint32_t key = f32_ord(x[c]), dig = (key >> shift) & 0xffu;
+                    if ((key & himask) == prefA) atomicAdd(&h[0][dig], 1u);
+                    if ((key & himask) == prefB) atomicAdd(&h[1][dig], 1u);
+                }
+        }
+    }
+    __syncthreads();
+    if (h[0][threadIdx.x]) atomicAdd(hist + threadIdx.x, (unsigned long long)h[0][threadIdx.x]);
+    if (h[1][threadIdx.x]) atomicAdd(hist + 256 + threadIdx.x, (unsigned long long)h[1][threadIdx.x]);
+}
+
 // query_context (scalar.rs:236-240): sum(q) folded from -0.0, and ||q|| for the GEMM engine's error bound
 __global__ void query_sums_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, size_t ldq,
                                   float* __restrict__ qsum, float* __restrict__ qnorm) {
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(256) void scan_u8_filter_kernel(const uint8_t* __re
                                                              const float* __restrict__ qsum, float a255, float offset,
                                                              uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
                                                              uint32_t qstride, uint32_t KP, uint32_t chunks_per_slot,
-                                                             uint32_t* __restrict__ errflag) {
+                                                             uint32_t* __restrict__ errflag, uint32_t nvalid = 0xFFFFFFFFu) {
     constexpr uint32_t cap = 64 * R;
     __shared__ uint32_t s_cnt[4][QB];
     __shared__ uint32_t s_thr[4][QB];
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(256) void scan_u8_filter_kernel(const uint8_t* __re
                     const int c = 4 * c4 + cc;
                     const size_t i = col + c;
                     const uint32_t pref = f32_ord(u8_score(a255, acc[j][c], offset, qs));
-                    if (i < N && pref >= thr)
+                    if (i < N && pref >= thr && qoff + j < nvalid)  // (beyond nvalid: zero rows padding a ragged query tail)
                         cand_append(my_lists + (size_t)j * cap, &s_cnt[w][j], cap, cand_make(pref, (uint32_t)i), errflag);
                 }
             }

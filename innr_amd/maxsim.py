@@ -88,6 +88,42 @@ class DocumentCorpus:
         check(load().innr_maxsim_generate(ctx.handle, ndocs, T, dim, C.c_uint64(seed), C.c_uint64(row0), C.byref(h)))
         return cls(h, ndocs, T, dim, ctx)
 
+    # ---- persistence: tokens in their device order [doc][token][dim] behind a 40-byte header (cf. VerticalBatch.save) ----
+    _MAGIC = b"INNRDOC1"  # magic, u64 docs, u64 T, u64 dim, u64 has_doc_len, then docs*T*dim f32, then [docs u32 lengths]
+
+    def save(self, path: str) -> None:
+        has = C.c_int(0)
+        check(load().innr_docs_shape(self._h, None, None, None, C.byref(has)))
+        ntok = self._n * self._T * self._dim
+        with open(path, "wb") as f:
+            f.write(self._MAGIC + np.array([self._n, self._T, self._dim, has.value], dtype="<u8").tobytes())
+            f.truncate(40 + 4 * ntok + (4 * self._n if has.value else 0))
+        if ntok:
+            tok = np.memmap(path, dtype="<f4", mode="r+", offset=40, shape=(ntok,))
+            dl = np.empty(self._n, np.uint32) if has.value else None
+            check(load().innr_docs_download(self._h, C.c_void_p(tok.ctypes.data), C.c_void_p(dl.ctypes.data) if dl is not None else None))
+            tok.flush()
+            del tok
+            if dl is not None:
+                with open(path, "r+b") as f:
+                    f.seek(40 + 4 * ntok)
+                    f.write(dl.astype("<u4").tobytes())
+
+    @classmethod
+    def load(cls, path: str, ctx: Optional[_lib.Context] = None) -> "DocumentCorpus":
+        import os
+        with open(path, "rb") as f:
+            head = f.read(40)
+        if len(head) != 40 or head[:8] != cls._MAGIC:
+            raise InnrPanic(f"{path}: not an innr document corpus file")
+        n, T, dim, has = (int(x) for x in np.frombuffer(head[8:], dtype="<u8"))
+        ntok = n * T * dim
+        if os.path.getsize(path) != 40 + 4 * ntok + (4 * n if has else 0):
+            raise InnrPanic(f"{path}: size does not match its header ({n} x {T} x {dim})")
+        tok = np.memmap(path, dtype="<f4", mode="r", offset=40, shape=(n, T, dim)) if ntok else np.empty((n, T, dim), np.float32)
+        dl = np.fromfile(path, dtype="<u4", count=n, offset=40 + 4 * ntok) if has else None
+        return cls.from_tokens(tok, dl, ctx)
+
     def set_index_base(self, base: int) -> None:
         """Global index of this shard's first document (multi-GPU range partition)."""
         check(load().innr_docs_set_index_base(self._h, C.c_uint64(int(base))))

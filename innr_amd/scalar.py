@@ -224,6 +224,40 @@ class QuantizedCorpus:
         r = int(out_k.value)
         return idx[:, :r].reshape(nq, r), sc[:, :r].reshape(nq, r)
 
+    # ---- persistence: the codes in their device order data[d*N + i] behind a 32-byte header (cf. VerticalBatch.save) -----
+    _MAGIC = b"INNRU8C1"  # magic, u64 n, u64 dim, f32 alpha, f32 offset, then dim x n bytes
+
+    def save(self, path: str) -> None:
+        """Write the code corpus and its QuantizationParams; the device copy goes straight into the memory-mapped file."""
+        with open(path, "wb") as f:
+            f.write(self._MAGIC + np.array([self._n, self._d], dtype="<u8").tobytes() +
+                    np.array([self.params.alpha, self.params.offset], dtype="<f4").tobytes())
+            f.truncate(32 + self._n * self._d)
+        if self._n * self._d:
+            mm = np.memmap(path, dtype=np.uint8, mode="r+", offset=32, shape=(self._d * self._n,))
+            check(load().innr_batch_download_u8(self._h, _vp(mm)))
+            mm.flush()
+            del mm
+
+    @classmethod
+    def load(cls, path: str, ctx: Optional[_lib.Context] = None) -> "QuantizedCorpus":
+        """Inverse of save(): the file is memory-mapped and uploaded as it is (already the device's layout order)."""
+        import os
+        with open(path, "rb") as f:
+            head = f.read(32)
+        if len(head) != 32 or head[:8] != cls._MAGIC:
+            raise InnrPanic(f"{path}: not an innr u8 corpus file")
+        n, d = (int(x) for x in np.frombuffer(head[8:24], dtype="<u8"))
+        alpha, offset = (float(x) for x in np.frombuffer(head[24:32], dtype="<f4"))
+        if os.path.getsize(path) != 32 + n * d:
+            raise InnrPanic(f"{path}: size does not match its header ({n} x {d})")
+        ctx = ctx or default_context()
+        h = C.c_void_p()
+        mm = np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(d * n,)) if n * d else np.empty(0, np.uint8)
+        check(load().innr_batch_upload_u8_colmajor(ctx.handle, _vp(mm) if n * d else None, n, d, C.c_float(alpha), C.c_float(offset),
+                                                   C.byref(h)))
+        return cls(h, n, d, QuantizationParams(alpha, offset), ctx)
+
     def prefix(self, prefix_dims: int) -> "QuantizedCorpus":
         """The corpus restricted to the first min(prefix_dims, dim) code dimensions (same params): a view of the leading
         rows of the dimension-major code matrix, cf. VerticalBatch.prefix. Closing the parent closes its views."""
@@ -258,6 +292,18 @@ def fit_batch(batch) -> QuantizationParams:
     if not any_.value:  # empty (scalar.rs:69-74); an all-NaN corpus leaves min > max in the reference: same result
         return QuantizationParams(1.0, 0.0)
     return QuantizationParams.from_range(float(mn.value), float(mx.value))
+
+
+def fit_quantile_batch(batch, quantile: float) -> QuantizationParams:
+    """QuantizationParams::fit_quantile (scalar.rs:104-139) over every value of a device-resident f32 VerticalBatch: the two
+    rank values come from a radix select on the device (no sort, no download of the corpus)."""
+    if not (0.0 < quantile <= 1.0):
+        raise InnrPanic("quantile must be in (0.0, 1.0]")
+    lo, hi, any_ = C.c_float(0.0), C.c_float(0.0), C.c_int(0)
+    check(load().innr_batch_quantile_range(batch._h, C.c_float(quantile), C.byref(lo), C.byref(hi), C.byref(any_)))
+    if not any_.value:
+        return QuantizationParams(1.0, 0.0)
+    return QuantizationParams.from_range(float(lo.value), float(hi.value))
 
 
 def two_stage_knn(queries, coarse: "QuantizedCorpus", fine, k: int, k_coarse: int, metric: Optional[int] = None):

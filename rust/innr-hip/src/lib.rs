@@ -60,6 +60,7 @@ pub mod ffi {
         pub fn innr_batch_upload_u8(ctx: *mut InnrCtx, codes: *const u8, n: usize, d: usize, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_generate_u8(ctx: *mut InnrCtx, n: usize, d: usize, seed: u64, row0: u64, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_download_u8(b: *mut InnrBatch, out: *mut u8) -> c_int;
+        pub fn innr_batch_upload_u8_colmajor(ctx: *mut InnrCtx, data: *const u8, n: usize, d: usize, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_scores_u8(b: *mut InnrBatch, q: *const f32, d: usize, out: *mut f32) -> c_int;
         pub fn innr_batch_knn_u8(b: *mut InnrBatch, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
         pub fn innr_batch_knn_u8_dev(b: *mut InnrBatch, d_queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
@@ -67,10 +68,13 @@ pub mod ffi {
         pub fn innr_mixed_dot_u8_f32(a: *const f32, b: *const u8, n: usize) -> f32;
         pub fn innr_batch_quantize_u8(f32_batch: *mut InnrBatch, alpha: f32, offset: f32, out: *mut *mut InnrBatch) -> c_int;
         pub fn innr_batch_minmax(f32_batch: *mut InnrBatch, out_min: *mut f32, out_max: *mut f32, out_any: *mut c_int) -> c_int;
+        pub fn innr_batch_quantile_range(f32_batch: *mut InnrBatch, quantile: f32, out_lo: *mut f32, out_hi: *mut f32, out_any: *mut c_int) -> c_int;
         pub fn innr_maxsim_upload(ctx: *mut InnrCtx, tokens: *const f32, doc_len: *const u32, docs: usize, t: usize, dim: usize, out: *mut *mut InnrDocs) -> c_int;
         pub fn innr_maxsim_generate(ctx: *mut InnrCtx, docs: usize, t: usize, dim: usize, seed: u64, row0: u64, out: *mut *mut InnrDocs) -> c_int;
         pub fn innr_docs_free(d: *mut InnrDocs);
         pub fn innr_docs_count(d: *const InnrDocs) -> usize;
+        pub fn innr_docs_shape(d: *const InnrDocs, ndocs: *mut usize, t: *mut usize, dim: *mut usize, has_doc_len: *mut c_int) -> c_int;
+        pub fn innr_docs_download(d: *mut InnrDocs, tokens: *mut f32, doc_len: *mut u32) -> c_int;
         pub fn innr_docs_set_index_base(d: *mut InnrDocs, base: u64) -> c_int;
         pub fn innr_maxsim_scores(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, out: *mut f32) -> c_int;
         pub fn innr_maxsim_topk(d: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int, out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;

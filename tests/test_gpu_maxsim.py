@@ -215,3 +215,27 @@ def test_maxsim_topk_multi_equals_single_queries(M, ndocs, T, dim, k):
     assert idx[1].tolist() == i1.tolist() and bits_equal(sc[1], s1)
     idx, sc = dc.topk_multi([], k)
     assert idx.shape[0] == 0
+
+
+def test_document_corpus_save_load_roundtrip(tmp_path):
+    import innr_amd
+    from innr_amd import maxsim as M
+    ndocs, T, dim = 300, 20, 24
+    tok = oracle.generate_uniform(ndocs * T, dim, 5).reshape(ndocs, T, dim)
+    lens = (np.arange(ndocs) % T + 1).astype(np.uint32)
+    q = oracle.generate_uniform(6, dim, 9)
+    for doc_len in (None, lens):
+        dc = M.DocumentCorpus.from_tokens(tok, doc_len)
+        path = str(tmp_path / "docs.bin")
+        dc.save(path)
+        back = M.DocumentCorpus.load(path)
+        assert len(back) == ndocs
+        a, b = dc.scores(q), back.scores(q)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        i1, s1 = dc.topk(q, 11)
+        i2, s2 = back.topk(q, 11)
+        assert np.array_equal(i1, i2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    with open(path, "r+b") as f:
+        f.write(b"XXXXXXXX")
+    with pytest.raises(innr_amd.InnrPanic):
+        M.DocumentCorpus.load(path)

@@ -336,10 +336,11 @@ def test_config5_cosine_4096_queries_two_logical_shards(B, innr):
     ctx.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
 def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves, monkeypatch):
-    # plan_gemm picks 8-wave (512-query) tiles for dot and 4-wave tiles for cosine / L2; INNR_GEMM_WAVES forces either,
-    # so every (kind, block shape) instantiation stays under test
+    # plan_gemm picks 8-wave (512-query) tiles for dot with many queries, 4-wave tiles for cosine / L2, 1- and 2-wave
+    # (64- / 128-query) tiles for small batches; INNR_GEMM_WAVES forces any of them, so every (kind, block shape)
+    # instantiation stays under test -- here with 600 queries, i.e. ten 64-query tiles down to two 512-query ones
     monkeypatch.setenv("INNR_GEMM_WAVES", waves)
     rows, data = _corpus(70_000, 64, 31, uniform=True)
     vb = None

@@ -324,3 +324,64 @@ def test_rerank_and_ingest_edge_cases(S, innr):
     assert (p.alpha, p.offset) == (1.0, 2.5)
     with pytest.raises(innr.InnrError):
         S.QuantizedCorpus.from_batch(S.QuantizedCorpus.from_codes(np.zeros((2, 2), np.uint8), 2, 2, p), p)  # not an f32 batch
+
+
+@pytest.mark.parametrize("n,dim", [(1, 1), (257, 3), (3001, 37), (20_000, 64)])
+@pytest.mark.parametrize("quantile", [0.5, 0.9, 0.99, 0.999, 1.0])
+def test_device_fit_quantile_matches_reference_ranks(S, innr, n, dim, quantile):
+    """QuantizationParams::fit_quantile (scalar.rs:104-139) on a resident batch: the two rank values of the FINITE values in
+    total_cmp order, found by a radix select on the device -- bit-equal alpha / offset to the oracle's sort-based version,
+    with NaN / +-inf / +-0.0 / duplicates / outliers in the data."""
+    from innr_amd import batch as B
+    rows = (oracle.generate_uniform(n, dim, 8) * np.float32(2.5) + np.float32(0.3)).astype(np.float32)
+    flat = rows.reshape(-1)
+    if flat.size > 50:
+        flat[5] = np.nan
+        flat[9] = 1e30
+        flat[11] = -np.inf
+        flat[12] = np.inf
+        flat[13] = -0.0
+        flat[14] = 0.0
+        flat[20:40] = flat[19]  # duplicates
+    vb = B.VerticalBatch.from_rows(rows)
+    p = S.fit_quantile_batch(vb, quantile)
+    hp = oracle.qparams_fit_quantile(rows.reshape(-1), quantile)
+    assert np.float32(p.alpha).view(np.uint32) == np.float32(hp.alpha).view(np.uint32), (p, hp.alpha, hp.offset)
+    assert np.float32(p.offset).view(np.uint32) == np.float32(hp.offset).view(np.uint32), (p, hp.alpha, hp.offset)
+
+
+def test_device_fit_quantile_edge_cases(S, innr):
+    from innr_amd import batch as B
+    vb = B.VerticalBatch.from_rows(np.full((4, 3), np.nan, np.float32))
+    p = S.fit_quantile_batch(vb, 0.9)
+    assert (p.alpha, p.offset) == (1.0, 0.0)  # no finite value (scalar.rs:124-129)
+    with pytest.raises(innr.InnrPanic):
+        S.fit_quantile_batch(vb, 0.0)  # "quantile must be in (0.0, 1.0]"
+    with pytest.raises(innr.InnrPanic):
+        S.fit_quantile_batch(vb, 1.5)
+    const = B.VerticalBatch.from_rows(np.full((10, 2), 0.25, np.float32))
+    p = S.fit_quantile_batch(const, 0.5)
+    assert (p.alpha, p.offset) == (1.0, 0.25)  # zero range -> alpha 1 (scalar.rs:57)
+
+
+def test_quantized_corpus_save_load_roundtrip(S, innr, tmp_path):
+    n, dim = 2049, 37
+    p = S.QuantizationParams(3.5, -0.25)
+    codes = _codes(n, dim, 13, p.alpha, p.offset)
+    qc = S.QuantizedCorpus.from_codes(codes, n, dim, p)
+    path = str(tmp_path / "corpus.u8")
+    qc.save(path)
+    back = S.QuantizedCorpus.load(path)
+    assert len(back) == n and back.dimension() == dim and back.params == p
+    assert np.array_equal(back.codes(), codes)
+    q = oracle.generate_uniform(3, dim, 2)
+    i1, s1 = qc.knn_multi(q, 7)
+    i2, s2 = back.knn_multi(q, 7)
+    assert np.array_equal(i1, i2) and bits_equal(s1, s2)
+    with open(path, "r+b") as f:
+        f.write(b"XXXXXXXX")
+    with pytest.raises(innr.InnrPanic):
+        S.QuantizedCorpus.load(path)
+    empty = S.QuantizedCorpus.from_codes(np.empty((0, 5), np.uint8), 0, 5, p)
+    empty.save(path)
+    assert len(S.QuantizedCorpus.load(path)) == 0

@@ -86,8 +86,9 @@ def pmc_traffic(args):
     section HBM; calibrated here on norms_kernel: 1.50e7 KB reported for a 30.72 GB read)."""
     default = (args.n_per_gpu, args.dim, args.queries, args.k, args.metric) == (10_000_000, 768, 1024, 10, "dot")
     vals = {}
+    rnd = next((r for r in ("r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_bench_n1_pmc_FETCH_SIZE.csv"))), "r01")
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r01_bench_n1_pmc_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"{rnd}_bench_n1_pmc_{name}.csv")
         if not default or not os.path.exists(path):
             return {"traffic": None}
         for line in open(path):
@@ -97,7 +98,7 @@ def pmc_traffic(args):
         return {"traffic": None}
     rd, wr = vals["FETCH_SIZE"] * 1024.0 * 2.0, vals["WRITE_SIZE"] * 1024.0
     return {"traffic": rd + wr, "traffic_unit": "bytes per launch",
-            "traffic_source": "profiles/r01_bench_n1_pmc_{FETCH,WRITE}_SIZE.csv (FETCH_SIZE x2 gfx950 correction; "
+            "traffic_source": f"profiles/{rnd}" + "_bench_n1_pmc_{FETCH,WRITE}_SIZE.csv (FETCH_SIZE x2 gfx950 correction; "
                               "L2-miss side, Infinity-Cache hits included)",
             "algorithmic_bytes_per_launch": 4.0 * args.n_per_gpu * args.dim}
 
@@ -113,6 +114,7 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", choices=["dot", "cosine"], default="dot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-rows", action="store_true", help="skip the bf16-filter side measurement of the default run")
     ap.add_argument("--data", choices=["uniform", "lcg"], default="uniform",
                     help="uniform: i.i.d. uniform(-1,1), the distribution of the reference's criterion benches (default, the "
                          "judged row); lcg: the reference EXAMPLE's generator (examples/batch_demo.rs:233-242: corpus row i = "
@@ -258,6 +260,27 @@ def main() -> None:
                 **(pmc_traffic(args) if args.engine == "f32" else {"traffic": None}),
             },
         }
+        if world == 1 and args.engine == "f32" and args.data == "uniform" and not args.no_side_rows:
+            # side row (not `value`): the same call with the filter stage on the bf16 matrix pipe -- INNR_KNN_MFMA_BF16, what
+            # INNR_KNN_AUTO picks for such a batch -- and a check that it returns the f32 engine's answer bit for bit
+            f_idx, f_sc = idx.clone(), sc.clone()
+            bl = _gpu_local_search(vb, metric, KNN_MFMA_BF16)
+            st2 = KnnStats()
+            bl(q_dev, args.k, st2)  # builds the K-packed bf16 corpus copy
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                st2 = KnnStats()
+                b_idx, b_sc = bl(q_dev, args.k, st2)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t1) / args.steps
+            out["bf16_filter_engine"] = {
+                "ms_per_step": dt2 * 1e3, "value": args.queries * n_total / dt2, "unit": "vectors/s", "kernel_ms": st2.gemm_ms,
+                "kernel": "gemm_bf16_filter_kernel (v_mfma_f32_32x32x16_bf16)",
+                "kernel_frac_of_bf16_peak": flop / (st2.gemm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if st2.gemm_ms > 0 else None,
+                "queries_redone": int(st2.queries_fallback), "candidates_per_query": int(st2.candidates_kept),
+                "identical_to_f32_engine": bool(torch.equal(f_idx, b_idx) and torch.equal(f_sc.view(torch.int32), b_sc.view(torch.int32))),
+            }
         if args.data == "lcg":
             # every proof fails on this data: the step is the GEMM pass + ceil(redone / 8) exact corpus passes (HBM-bound)
             nredo = float(np.mean(fallbacks))

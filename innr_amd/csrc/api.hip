@@ -177,6 +177,7 @@ struct innr_batch {
     bool is_view = false, gemm_ok = true;
     // bf16 filter engine (kernels_gemm_bf16.h): K-packed bf16 copy of the corpus, built on first use, always owned
     char* Ab = nullptr;
+    char* Abn = nullptr;  // the same with every row scaled by 1/||v||: the cosine filter (built on the first cosine call)
     uint32_t ab_nk = 0;
     // int8 filter engine (kernels_gemm_i8.h): K-packed signed copy of the u8 codes, built on first use, always owned
     char* Ai8 = nullptr;
@@ -667,24 +668,28 @@ static innr_status redo_batch(innr_batch* b, int metric, const float* dQ, const 
 
 static uint32_t bf16_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 64) / 32); }  // K-steps of 32, even
 
-static innr_status ensure_bf16_corpus(innr_batch* b) {
-    if (b->Ab) return INNR_OK;
+static size_t bf16_copy_bytes(const innr_batch* b) { return (b->ldN / 128) * (size_t)bf16_nk(b) * 512 * 16; }
+
+// normalised == true: the cosine copy (rows scaled by 1/||v||; needs b->invn)
+static innr_status ensure_bf16_corpus(innr_batch* b, bool normalised) {
+    char*& copy = normalised ? b->Abn : b->Ab;
+    if (copy) return INNR_OK;
     const uint32_t nk = bf16_nk(b);
     const size_t units = (b->ldN / 128) * (size_t)nk * 512;  // 16-byte units
-    hipError_t e = hipMalloc((void**)&b->Ab, units * 16);
+    hipError_t e = hipMalloc((void**)&copy, units * 16);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu bytes) for the bf16 corpus copy failed: %s", units * 16, hipGetErrorString(e));
-        b->Ab = nullptr;
+        copy = nullptr;
         return INNR_E_OOM;
     }
-    pack_corpus_bf16_kernel<<<(unsigned)((units + 255) / 256), 256, 0, b->ctx->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk,
-                                                                                     units, reinterpret_cast<uint4*>(b->Ab));
+    pack_corpus_bf16_kernel<<<(unsigned)((units + 255) / 256), 256, 0, b->ctx->stream>>>(
+        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk, units, reinterpret_cast<uint4*>(copy), normalised ? b->invn : nullptr);
     INNR_HIP_CHECK(hipGetLastError());
     b->ab_nk = nk;
     return INNR_OK;
 }
 
-static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed) {
+static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed, bool normalised) {
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
     const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
@@ -695,7 +700,7 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nre
     INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
 #define INNR_BF16_LAUNCH(RR)                                                                                              \
     gemm_bf16_filter_kernel<RR, 0><<<p.nblocks, 64 * kBfWaves, 0, c->stream>>>(                                             \
-        b->Ab, c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps,      \
+        normalised ? b->Abn : b->Ab, c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps, \
         c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, nullptr, 0)
     switch (p.cap) {
         case 384: INNR_BF16_LAUNCH(6); break;
@@ -714,9 +719,10 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
-    // bf16 filter: dot kind, candidate lists of 4k + 64 (its bound E is ~2^-7 |q||v|, so the k-th exact score must clear
-    // the KP-th approximate one by a visible margin), a corpus whose scores are far from the denormal range
-    const bool use_bf16 = bf16 && !cos && !l2 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
+    // bf16 filter: dot and cosine kinds (cosine = the plain dot of NORMALISED bf16 copies of corpus and queries: no norm is
+    // loaded in the kernel), candidate lists of 4k + 64 (its bound E is ~2^-7 |q||v|, so the k-th exact score must clear the
+    // KP-th approximate one by a visible margin), a corpus whose scores are far from the denormal range
+    const bool use_bf16 = bf16 && !l2 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
                           (b->max_norm - b->max_norm == 0.0f);
     GemmPlan p = plan_gemm(b, Q, kout, use_bf16 ? 8 : 0, !cos && !l2);
     if (kp_force && !use_bf16 && kp_force >= p.KP && kp_force <= 256) {  // second attempt of redo_batch: longer lists
@@ -726,15 +732,18 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     if (use_bf16) {
         p.KP = pick_kp(4 * kout + 64, 0);
         p.cap = (uint32_t)cand_cap((int)p.KP);
-        INNR_TRY(ensure_bf16_corpus(b));
-        INNR_TRY(c->q_bf16.ensure((size_t)b->ab_nk * 4 * p.Qpad * 16));
-        pack_queries_bf16_kernel<<<(unsigned)(((size_t)b->ab_nk * 4 * p.Qpad + 255) / 256), 256, 0, c->stream>>>(
-            dQ, (uint32_t)Q, (uint32_t)b->D, b->ab_nk, (uint32_t)p.Qpad, reinterpret_cast<uint4*>(c->q_bf16.p));
-        INNR_HIP_CHECK(hipGetLastError());
     }
     if (cos) INNR_TRY(ensure_invnorms(b));
     if (l2) INNR_TRY(ensure_sqnorms(b));
-    INNR_TRY(prep_queries(b, p, dQ, Q, cos));
+    INNR_TRY(prep_queries(b, p, dQ, Q, cos));  // K-major queries, exact query norms (c->q_norm), cosine: 1/||q|| at c->misc
+    if (use_bf16) {
+        INNR_TRY(ensure_bf16_corpus(b, cos));
+        INNR_TRY(c->q_bf16.ensure((size_t)b->ab_nk * 4 * p.Qpad * 16));
+        pack_queries_bf16_kernel<<<(unsigned)(((size_t)b->ab_nk * 4 * p.Qpad + 255) / 256), 256, 0, c->stream>>>(
+            dQ, (uint32_t)Q, (uint32_t)b->D, b->ab_nk, (uint32_t)p.Qpad, reinterpret_cast<uint4*>(c->q_bf16.p),
+            cos ? c->misc.as<float>() : nullptr);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
@@ -760,7 +769,8 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
     // bf16 filter: both operands rounded to 8 significant bits (|delta| <= 2^-8 each): |q'v' - qv| <= (2^-7 + 2^-16) |qv|,
     // plus the f32 accumulation of the rounded products
-    const float bf16_scale = 1.05f * (0.0078125f * 1.004f + (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f * 1.02f) * b->max_norm;
+    // (cosine: both sides normalised before the rounding, |q^||v^| <= (1 + D u)^2 -- inside the 1.05)
+    const float bf16_scale = 1.05f * (0.0078125f * 1.004f + (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f * 1.02f) * (cos ? 1.0f : b->max_norm);
     const float err_scale = use_bf16 ? bf16_scale
                                      : (l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm));
 
@@ -786,9 +796,9 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     }
 
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
+    if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed, cos));
+    else if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
     else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, Q, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
-    else if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed));
     // (A first pass of the same kernel over 1/16 of the corpus, only to harvest tighter bounds for the full pass, was
     //  tried: 17.6 ms for both against 16.4 for the single pass.)
     else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
@@ -820,7 +830,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     if (use_bf16) INNR_HIP_CHECK(copy_out(c, qn_host.data(), c->q_norm.p, Q * sizeof(float)));
     INNR_HIP_CHECK(ctx_sync(c));
     // bf16 products / sums below the normal range may be flushed to zero: the bound E must dwarf that, else redo exactly
-    for (size_t q = 0; q < qn_host.size(); ++q)
+    for (size_t q = 0; q < qn_host.size() && !cos; ++q)
         if (!(qn_host[q] * b->max_norm >= 1e-25f)) fb[q] = 1;
     // A non-finite corpus value (max_norm is then NaN or inf) voids every error bound -- for cosine too, whose bound does
     // not carry max_norm: NaN * 0 approximations can differ from the reference's 0.0 (batch.rs:722) by more than E.
@@ -1065,6 +1075,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->sqn) (void)hipFree(b->sqn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
     if (b->Ab) (void)hipFree(b->Ab);
+    if (b->Abn) (void)hipFree(b->Abn);
     if (b->Ai8) (void)hipFree(b->Ai8);
     delete b;
 }
@@ -1451,7 +1462,19 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     INNR_ENTER(c);
     // AUTO: the GEMM engine pays off once there are enough queries to fill MFMA tiles AND enough corpus per slice
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
-    if (engine == INNR_KNN_AUTO) engine = innr_batch_auto_engine(b, Q);
+    if (engine == INNR_KNN_AUTO) {
+        engine = innr_batch_auto_engine(b, Q);
+        // The bf16 filter (identical results, ~6x the f32 engine's rate at C2) when it applies -- dot / cosine, k <= 48, a
+        // batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
+        // everything else with room to spare (the copy is N*D*2 bytes and is kept for the batch's lifetime).
+        if (engine == INNR_KNN_MFMA && Q >= 128 && metric != INNR_METRIC_L2SQ && pick_kp(4 * kout + 64, 0) <= 256 &&
+            !getenv("INNR_NO_AUTO_BF16")) {
+            const bool have = metric == INNR_METRIC_COSINE ? b->Abn != nullptr : b->Ab != nullptr;
+            size_t free_b = 0, total_b = 0;
+            if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * bf16_copy_bytes(b) + ((size_t)8 << 30)))
+                engine = INNR_KNN_MFMA_BF16;
+        }
+    }
     if (engine == INNR_KNN_MFMA_I8) engine = INNR_KNN_MFMA;  // the int8 filter is the code corpora's (innr_batch_knn_u8)
     if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction

@@ -36,19 +36,23 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
 }
 
 // one thread per 16-byte output unit (8 dimensions of one corpus row)
+// rowscale (nullable): 1/||v|| per row (0 for zero-norm rows) -- the COSINE copy holds the normalised rows, so that the plain
+// dot of the filter kernel IS the approximate cosine (with the queries normalised the same way) and no norm is loaded per tile
 __global__ __launch_bounds__(256) void pack_corpus_bf16_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
-                                                                uint32_t nk, size_t units, uint4* __restrict__ Ab) {
+                                                                uint32_t nk, size_t units, uint4* __restrict__ Ab,
+                                                                const float* __restrict__ rowscale = nullptr) {
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= units) return;
     const uint32_t i = (uint32_t)(u & 31), rt = (uint32_t)((u >> 5) & 3), kg = (uint32_t)((u >> 7) & 3);
     const size_t tk = u >> 9;  // tile * nk + ks
     const uint32_t ks = (uint32_t)(tk % nk);
     const size_t row = (tk / nk) * 128 + 4 * i + rt;
+    const float rs = (rowscale && row < N) ? rowscale[row] : 1.0f;
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const uint32_t d = ks * 32 + kg * 8 + e;
-        h[e] = (row < N && d < D) ? f32_to_bf16_rne(V[(size_t)d * ldN + row]) : (uint16_t)0;
+        h[e] = (row < N && d < D) ? f32_to_bf16_rne(V[(size_t)d * ldN + row] * rs) : (uint16_t)0;
     }
     uint4 o;
     o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);
@@ -58,17 +62,19 @@ __global__ __launch_bounds__(256) void pack_corpus_bf16_kernel(const float* __re
 
 // queries row-major [Q][D] -> Bb; one thread per 16-byte unit
 __global__ __launch_bounds__(256) void pack_queries_bf16_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, uint32_t nk,
-                                                                 uint32_t Qpad, uint4* __restrict__ Bb) {
+                                                                 uint32_t Qpad, uint4* __restrict__ Bb,
+                                                                 const float* __restrict__ qscale = nullptr) {
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= (size_t)nk * 4 * Qpad) return;
     const uint32_t pos = (uint32_t)(u % Qpad);
     const uint32_t kk = (uint32_t)(u / Qpad);  // ks * 4 + kg
     const uint32_t q = (pos & ~63u) + 2 * (pos & 31) + ((pos >> 5) & 1);
+    const float qs = (qscale && q < Q) ? qscale[q] : 1.0f;  // cosine: 1/||q|| (0 below the reference's epsilon)
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const uint32_t d = kk * 8 + e;
-        h[e] = (q < Q && d < D) ? f32_to_bf16_rne(Qm[(size_t)q * D + d]) : (uint16_t)0;
+        h[e] = (q < Q && d < D) ? f32_to_bf16_rne(Qm[(size_t)q * D + d] * qs) : (uint16_t)0;
     }
     uint4 o;
     o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);

@@ -16,16 +16,40 @@ from test_gpu_exact import B, _check_knn, _corpus, _queries, bits_equal, innr, s
                                         (257, 33, 5, 16), (1000, 64, 9, 33), (5, 3, 2, 10), (200_000, 32, 40, 1)])
 def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k):
     rows, data = _corpus(n, dim, 77, uniform=True)
+    rows = (rows * (1.0 + 0.5 * np.sin(np.arange(n, dtype=np.float32)))[:, None]).astype(np.float32)  # unequal norms: cosine != dot order
+    data = oracle.from_rows(rows)
     vb = B.VerticalBatch.from_rows(rows)
     qs = _queries(nq, dim, 4242, uniform=True)
+    for metric, fn, ofn in (("dot", B.batch_knn_dot_multi, oracle.batch_knn_dot), ("cos", B.batch_knn_cosine_multi, oracle.batch_knn_cosine)):
+        st = innr.KnnStats()
+        idx, sc = fn(qs, vb, k, engine=innr.KNN_MFMA_BF16, stats=st)
+        assert st.engine == innr.KNN_MFMA_BF16
+        for j, q in enumerate(qs):
+            oi, os_ = ofn(q, data, k)
+            assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j, idx[j], oi, sc[j], os_)
+        if n >= 10_000:  # well-separated uniform data: (almost) every answer is proven, few queries redone exactly
+            assert st.queries_fallback <= max(2, nq // 20), (metric, st.queries_fallback)
+
+
+def test_bf16_cosine_zero_norms_and_auto(B, innr):
+    """cosine on the normalised bf16 copies with zero-norm rows and a zero query (the reference's epsilon guards,
+    batch.rs:716-727), and INNR_KNN_AUTO choosing the bf16 filter for a large batch with small k (same answers)"""
+    rows, data = _corpus(70_000, 48, 21, uniform=True)
+    rows[5] = 0.0
+    rows[777] = 1e-12
+    data = oracle.from_rows(rows)
+    qs = _queries(130, 48, 5, uniform=True)
+    qs[3] = 0.0
+    vb = _check_knn(B, innr, "cos", rows, data, qs, 10, innr.KNN_MFMA_BF16)
     st = innr.KnnStats()
-    idx, sc = B.batch_knn_dot_multi(qs, vb, k, engine=innr.KNN_MFMA_BF16, stats=st)
-    assert st.engine == innr.KNN_MFMA_BF16
-    for j, q in enumerate(qs):
-        oi, os_ = oracle.batch_knn_dot(q, data, k)
-        assert same_knn("dot", idx[j], sc[j], oi, os_), (j, idx[j], oi, sc[j], os_)
-    if n >= 10_000:  # well-separated uniform data: (almost) every answer is proven, few queries redone exactly
-        assert st.queries_fallback <= max(2, nq // 20), st.queries_fallback
+    B.batch_knn_cosine_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
+    assert st.engine == innr.KNN_MFMA_BF16  # the copy exists (and there is room for another): AUTO takes the fast filter
+    _check_knn(B, innr, "cos", vb, data, qs, 10, innr.KNN_AUTO)
+    _check_knn(B, innr, "dot", vb, data, qs, 10, innr.KNN_AUTO)
+    B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
+    assert st.engine == innr.KNN_MFMA  # squared L2 stays on the f32 engine
+    B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_AUTO, stats=st)
+    assert st.engine == innr.KNN_MFMA  # k > 48: the candidate lists of the bf16 filter would not fit
 
 
 def test_bf16_filter_near_ties_are_redone_exactly(B, innr):
@@ -38,7 +62,7 @@ def test_bf16_engine_serves_other_kinds_on_the_f32_engine(B, innr):
     rows, data = _corpus(70_000, 64, 5, uniform=True)
     vb = B.VerticalBatch.from_rows(rows)
     qs = _queries(20, 64, 9, uniform=True)
-    for metric, fn in (("cos", B.batch_knn_cosine_multi), ("l2", B.batch_knn_multi)):
+    for metric, fn in (("l2", B.batch_knn_multi),):
         st = innr.KnnStats()
         fn(qs, vb, 10, engine=innr.KNN_MFMA_BF16, stats=st)
         assert st.engine == innr.KNN_MFMA

@@ -324,6 +324,12 @@ def test_config5_cosine_4096_queries_two_logical_shards(B, innr):
         sub = np.arange(0, nq, 293)[:14]  # 14 queries spread over the batch (two 8-query passes of the exact engine)
         ei, es = _gpu_local_search(vb, innr.METRIC_COSINE, innr.KNN_EXACT)(q_dev[torch.from_numpy(sub).to(dev)].contiguous(), k)
         assert np.array_equal(hi[sub], ei.cpu().numpy()) and bits_equal(hs[sub], es.cpu().numpy())
+        # the bf16 filter engine (what INNR_KNN_AUTO picks at this shape): normalised bf16 copies, same answers for all 4096
+        st2 = innr.KnnStats()
+        bi, bs = _gpu_local_search(vb, innr.METRIC_COSINE, innr.KNN_MFMA_BF16)(q_dev, k, st2)
+        torch.cuda.synchronize()
+        assert st2.engine == innr.KNN_MFMA_BF16 and torch.equal(bi, idx) and torch.equal(bs.view(torch.int32), sc.view(torch.int32))
+        print(f"C5 shard {r} on the bf16 filter: gemm {st2.gemm_ms:.1f} ms, total {st2.total_ms:.1f} ms, fallback {st2.queries_fallback}")
         vb.close()
     out_i, out_s = _gpu_merge(ctx, innr.METRIC_COSINE)(all_i, all_s, k)
     torch.cuda.synchronize()

@@ -167,7 +167,24 @@ def main() -> None:
     # N > 1: the exchange step runs inside the library (innr_sharded_knn_dev: local search + pack + ONE ncclAllGather of
     # 8-byte entries + merge) on an RCCL communicator it owns; torch.distributed only carries the communicator id.
     # (A one-GPU rehearsal with gloo has no RCCL: the same blocks then travel through torch.distributed.all_gather.)
-    comm = Comm.from_torch_group(ctx) if (world > 1 and dist.get_backend() == "nccl") else None
+    comm, exchange = None, "none (1 GPU)"
+    if world > 1 and dist.get_backend() == "nccl":
+        err = ""
+        try:
+            comm = Comm.from_torch_group(ctx)
+        except Exception as exc:  # no librccl / init failure on this rank
+            err = repr(exc)
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks take the same path
+        if int(ok.item()) == 1:
+            exchange = "innr_sharded_knn_dev: ncclAllGather of 8-byte candidates on the library's own RCCL communicator"
+        else:
+            if comm is not None:
+                comm.close()
+            comm = None
+            exchange = f"torch.distributed.all_gather of the same blocks (library communicator unavailable: {err or 'another rank failed'})"
+    elif world > 1:
+        exchange = "torch.distributed.all_gather of the same blocks through the host (gloo rehearsal)"
     sk = ShardedKnn(n_total, rank=rank, world=world, comm=comm) if world > 1 else None
     row0 = rank * args.n_per_gpu
     from innr_amd import GEN_EXAMPLE_LCG, GEN_UNIFORM
@@ -246,6 +263,7 @@ def main() -> None:
                 "candidates_per_query": int(kept),
                 "queries_redone_exactly_per_step": float(np.mean(fallbacks)),
                 "parallelism": f"range-partitioned corpus x{world}, all-gather of per-shard top-k" if world > 1 else "1 GPU",
+                "exchange": exchange,
             },
             "roofline": {
                 "bound": "mfma",

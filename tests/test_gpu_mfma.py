@@ -149,6 +149,23 @@ def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
     for j, q in enumerate(qs):
         oi, os_ = oracle.batch_knn(q, data, 5)
         assert same_knn("l2", idx[j], sc[j], oi, os_)
+    # cosine: its bound does not carry the corpus norm, yet a row with a NaN / inf component scores NaN * 0 on the matrix pipe
+    # where the reference says 0.0 (norm NaN -> `vn > eps` false, batch.rs:722) -- every query must take the exact engine. The
+    # corpus here is the NEGATED queries' neighbourhood: all finite cosines are negative, so the 0.0 of the broken rows is top-1.
+    neg = (-np.abs(oracle.generate_uniform(4000, 32, 2))).astype(np.float32)
+    neg[17, 3] = np.nan
+    neg[300, 0] = np.inf
+    qpos = np.abs(_queries(6, 32, 6, uniform=True)).astype(np.float32)
+    dneg = oracle.from_rows(neg)
+    for engine in (innr.KNN_MFMA, innr.KNN_MFMA_BF16):
+        vbn = B.VerticalBatch.from_rows(neg)
+        idx, sc = B.batch_knn_cosine_multi(qpos, vbn, 5, engine=engine, stats=st)
+        assert st.queries_fallback == len(qpos)
+        for j, q in enumerate(qpos):
+            oi, os_ = oracle.batch_knn_cosine(q, dneg, 5)
+            assert same_knn("cos", idx[j], sc[j], oi, os_), (engine, j, idx[j], oi, sc[j], os_)
+        oi, os_ = oracle.batch_knn_cosine(qpos[0], dneg, 5)
+        assert 17 in oi[:2].tolist() and 0.0 in os_[:2].tolist()  # the NaN-norm row scores 0.0 and leads the finite (negative) cosines
 
 
 def test_knn_auto_engine_selection(B, innr):

@@ -2002,9 +2002,19 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
 // ---- int8 filter engine (kernels_gemm_i8.h) -------------------------------------------------------------------------
 static uint32_t i8_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 128) / 64); }  // K-steps of 64, even
 
+// which int8 filter kernel: one limb on the matrix pipe + exact low-limb fix-up (default), or both limbs on the pipe
+// (INNR_I8_TWO_LIMB=1, and for candidate lists of 256: the one-limb kernel's visit path and a 1280-entry list compaction
+// do not fit the register file together -- tools/check_gemm_asm.py caught the operand ring being spilled)
+static bool i8_two_limb(size_t kout) {
+    const char* e = getenv("INNR_I8_TWO_LIMB");
+    return (e && atoi(e) != 0) || pick_kp(kout, 16) > 128;
+}
+static uint32_t i8_shift(bool two) { return two ? 8u : (uint32_t)kI8hS; }
+
 static bool i8_eligible(const innr_batch* b, size_t Q) {
     return b->C8 && b->alpha > 0.0f && (b->alpha - b->alpha == 0.0f) && (b->offset - b->offset == 0.0f) && b->D >= 1 &&
-           b->D <= 65535 && i8_limb_r1((uint32_t)b->D) >= 1 && b->ldN < ((size_t)1 << 31) && Q < ((size_t)1 << 24);
+           b->D <= 65535 && i8_limb_r1((uint32_t)b->D, 8) >= 1 && i8_limb_r1((uint32_t)b->D, (uint32_t)kI8hS) >= 1 &&
+           b->ldN < ((size_t)1 << 31) && Q < ((size_t)1 << 24);
 }
 
 static innr_status ensure_i8_corpus(innr_batch* b) {
@@ -2028,11 +2038,14 @@ static innr_status ensure_i8_corpus(innr_batch* b) {
 struct I8Plan {
     size_t Qpad;
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
+    bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
 };
 static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
     I8Plan p;
-    p.Qpad = round_up(Q, kI8BQ);
-    p.nqt = (uint32_t)(p.Qpad / kI8BQ);
+    p.two = i8_two_limb(kout);
+    const size_t bq = p.two ? (size_t)kI8BQ : (size_t)kI8hBQ;  // queries per block tile
+    p.Qpad = round_up(Q, bq);
+    p.nqt = (uint32_t)(p.Qpad / bq);
     p.KP = pick_kp(kout, 16);
     p.cap = (uint32_t)cand_cap((int)p.KP);
     p.ntiles = (uint32_t)(b->ldN / 128);
@@ -2062,10 +2075,15 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     uint32_t* gslots = c->gthr.as<uint32_t>();
     if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
-#define INNR_I8_LAUNCH(RR)                                                                                                  \
-    gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(                                             \
-        b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc,                  \
-        c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump)
+    const bool two = p.two;
+#define INNR_I8_ARGS                                                                                                      \
+    b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
+        c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump
+#define INNR_I8_LAUNCH(RR)                                                                                                \
+    do {                                                                                                                  \
+        if (two) gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                  \
+        else gemm_i8h_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                     \
+    } while (0)
     if constexpr (MODE == 1) {
         INNR_I8_LAUNCH(6);
     } else {
@@ -2073,10 +2091,13 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
             case 384: INNR_I8_LAUNCH(6); break;
             case 512: INNR_I8_LAUNCH(8); break;
             case 768: INNR_I8_LAUNCH(12); break;
-            default: INNR_I8_LAUNCH(20); break;
+            default:  // lists of 256 candidates: the two-limb kernel only (plan_i8)
+                gemm_i8_filter_kernel<20, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);
+                break;
         }
     }
 #undef INNR_I8_LAUNCH
+#undef INNR_I8_ARGS
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
@@ -2085,10 +2106,10 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
 static innr_status prep_queries_i8(innr_batch* b, const I8Plan& p, const float* dQ, size_t Q, const float* qsum) {
     innr_ctx* c = b->ctx;
     INNR_TRY(c->q_bf16.ensure((size_t)b->ai8_nk * 8 * p.Qpad * 16));
-    INNR_TRY(c->misc.ensure(4 * p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
+    INNR_TRY(c->misc.ensure(5 * p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
     pack_queries_i8_kernel<<<(unsigned)p.Qpad, 64, 0, c->stream>>>(dQ, qsum, (uint32_t)Q, (uint32_t)b->D, b->ai8_nk, (uint32_t)p.Qpad,
-                                                                   i8_limb_r1((uint32_t)b->D), b->alpha / 255.0f, b->offset,
-                                                                   reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
+                                                                   i8_limb_r1((uint32_t)b->D, i8_shift(p.two)), i8_shift(p.two), b->alpha / 255.0f,
+                                                                   b->offset, reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
@@ -2101,7 +2122,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     const I8Plan p = plan_i8(b, Q, kout);
     INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum));
     const float* qc = c->misc.as<float>();
-    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 4 * p.Qpad * sizeof(float));
+    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
     const float a255 = b->alpha / 255.0f;
     // the reference's own f32 accumulation against the true sum: (D + 2) u ||q|| max||c||, ||c|| <= 255 sqrt(D) (the bound of
@@ -2171,7 +2192,7 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
     INNR_TRY(launch_gemm_i8<1>(b, p, Q, c->misc.as<float>(), c->scores.as<float>(), b->ldN));
     INNR_HIP_CHECK(hipMemcpy2DAsync(out, b->N * sizeof(float), c->scores.p, b->ldN * sizeof(float), b->N * sizeof(float), Q,
                                     hipMemcpyDeviceToHost, c->stream));
-    if (qc_out) INNR_HIP_CHECK(hipMemcpyAsync(qc_out, c->misc.p, 4 * p.Qpad * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (qc_out) INNR_HIP_CHECK(hipMemcpyAsync(qc_out, c->misc.p, 5 * p.Qpad * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (qpad_out) *qpad_out = p.Qpad;
     INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;

@@ -39,11 +39,15 @@ typedef int i32x16_t __attribute__((ext_vector_type(16)));
 constexpr int kI8Stages = 8, kI8Lead = 2, kI8StageBytes = 8192, kI8Waves = 8, kI8K = 64, kI8BQ = 256;
 static_assert(kI8Stages == 8 && kI8Lead == 2, "the one-barrier-per-two-steps schedule is derived for an 8-stage ring and a 2-step register ring");
 
-// largest 16-bit-fixed-point magnitude T = 256 R1 + 127 such that |V| <= D * 128 * T stays below 2^31
-__host__ __device__ inline uint32_t i8_limb_r1(uint32_t D) {
+// The query value is t = (r1 << S) + r2, r2 in [-2^(S-1), 2^(S-1) - 1], |r1| <= R1: the largest magnitude
+// T = (R1 << S) + 2^(S-1) - 1 such that |V| <= D * 128 * T stays below 2^31. S = 8: two full int8 limbs, both on the matrix
+// pipe (gemm_i8_filter_kernel); S = 6: a 14-bit value whose low limb is small enough to be bounded away in the filter and
+// computed only for the survivors (gemm_i8h_filter_kernel).
+__host__ __device__ inline uint32_t i8_limb_r1(uint32_t D, uint32_t S = 8) {
     const uint64_t tmax = (((uint64_t)1 << 31) - 1) / ((uint64_t)(D ? D : 1) * 128);
-    if (tmax < 127 + 256) return 0;  // not even one step of the high limb: the engine is off for this dimension
-    const uint64_t r1 = (tmax - 127) / 256;
+    const uint64_t lo_max = ((uint64_t)1 << (S - 1)) - 1;
+    if (tmax < lo_max + ((uint64_t)1 << S)) return 0;  // not even one step of the high limb: the engine is off for this dimension
+    const uint64_t r1 = (tmax - lo_max) >> S;
     return (uint32_t)(r1 > 127 ? 127 : r1);
 }
 
@@ -84,12 +88,14 @@ __global__ __launch_bounds__(256) void pack_corpus_i8_kernel(const uint8_t* __re
 //   |approx - (alpha/255 * true mixed dot + offset * sum q)| <= |alpha/255| s_j 64 D (quantisation, sum|c'| <= 128 D) + float
 //   rounding of A V + B (three roundings of values <= |A V| + |B|), with 2 % to spare; +inf when no finite scale exists
 //   (the proof then fails and the query takes the exact engine).
+//   qc[4][j] (as integer bits) = LOB_j = 128 * sum_d |r2_d| >= |sum_d c'_d r2_d|: the low limb's reach (gemm_i8h_filter_kernel)
 __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __restrict__ Qm, const float* __restrict__ qsum, uint32_t Q,
-                                                              uint32_t D, uint32_t nk, uint32_t Qpad, uint32_t R1, float a255,
+                                                              uint32_t D, uint32_t nk, uint32_t Qpad, uint32_t R1, uint32_t S, float a255,
                                                               float offset, uint4* __restrict__ Bq, float* __restrict__ qc) {
     const uint32_t j = blockIdx.x;
     const int lane = threadIdx.x;
-    const float T = (float)(256u * R1 + 127u);
+    const int half_lo = 1 << (S - 1);
+    const float T = (float)((R1 << S) + (uint32_t)half_lo - 1u);
     float mx = 0.0f;
     bool finite = true;
     if (j < Q)
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
     if (!usable) s = 1.0f;
     const float inv_s = 1.0f / s;
     const uint32_t nchunks = nk * 4;  // 16-dimension chunks
+    uint32_t abs_lo = 0;
     for (uint32_t c = lane; c < nchunks; c += 64) {
         uint32_t hi[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -117,8 +124,9 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
                 x = fminf(fmaxf(x, -T), T);
                 t = (int)x;
             }
-            const int r1 = (t + 128) >> 8;  // floor((t + 128) / 256): |r1| <= R1
-            const int r2 = t - 256 * r1;    // [-128, 127]
+            const int r1 = (t + half_lo) >> S;  // floor((t + 2^(S-1)) / 2^S): |r1| <= R1
+            const int r2 = t - (r1 << S);       // [-2^(S-1), 2^(S-1) - 1]
+            abs_lo += (uint32_t)(r2 < 0 ? -r2 : r2);
             hi[e >> 2] |= ((uint32_t)r1 & 0xffu) << (8 * (e & 3));
             lo[e >> 2] |= ((uint32_t)r2 & 0xffu) << (8 * (e & 3));
         }
@@ -126,6 +134,8 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
         Bq[((size_t)c * 2 + 0) * Qpad + j] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         Bq[((size_t)c * 2 + 1) * Qpad + j] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) abs_lo += (uint32_t)__shfl_xor((int)abs_lo, off, 64);
     if (lane == 0) {
         float A = 1.0f, B = 0.0f, E = 0.0f;
         if (j < Q) {
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
         qc[Qpad + j] = B;
         qc[2 * (size_t)Qpad + j] = 1.0f / A;
         qc[3 * (size_t)Qpad + j] = E;
+        qc[4 * (size_t)Qpad + j] = __int_as_float((int)(128u * abs_lo));  // < 2^31: abs_lo <= 2^(S-1) D, D <= 65535
     }
 }
 
@@ -426,6 +437,373 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
             if (lane == j) mine = keep;
         }
         if (lane < 32) counts[(size_t)slice * Qpad + q0 + 32 * w + lane] = mine;
+    }
+}
+
+
+// =====================================================================================================================
+// gemm_i8h_filter_kernel -- the same filter with ONE limb on the matrix pipe.
+//
+// The int8 filter is clock-limited: its time follows the MFMA work it executes, and the two-limb kernel
+// executes twice the algorithmic 2 Q N D. Here the query value is t = (r1 << 6) + r2 with a 6-bit low limb: only
+// hi = sum c' r1 runs on v_mfma_i32_32x32x32_i8; the low limb is BOUNDED in the fast reject,
+//     V = (hi << 6) + lo >= Tint   =>   hi >= (Tint - LOB_j) >> 6,     LOB_j = 128 sum_d |r2_d| >= |lo|,
+// and computed exactly (v_dot4_i32_i8 over the site's corpus row and the query's low limb, both read back from the packed
+// arrays) only for the sites that survive that test: ~1.6x the sites the full V would let through, a handful per tile. V is
+// then exact as before, so the candidates, the re-score and the proof are unchanged; the 14-bit query costs a 4x larger
+// quantisation bound than the 16-bit one (still ~1e-2 of the gap between neighbouring top scores at C3).
+// With one accumulator set per (row tile, query tile) a wave owns 64 queries again: block tile 128 rows x 512 queries, the
+// corpus streamed once per 512 queries, the bf16 kernel's operand reuse (an LDS fragment feeds 2 MFMAs, an L2 fragment 4).
+// =====================================================================================================================
+constexpr int kI8hBQ = 512, kI8hS = 6;
+
+struct alignas(16) GemmI8hLds {
+    alignas(16) char A[kI8Stages * kI8StageBytes];
+    uint32_t cnt[kI8hBQ];
+    uint32_t thr[kI8hBQ];
+};
+
+// lo(i, q) = sum_d c'_d r2_d of corpus row `row_in_tile` of tile `tile` and query column q, from the packed arrays
+__device__ __forceinline__ int32_t i8_lo_dot(const char* __restrict__ Ai8, const char* __restrict__ Bq, size_t tile, uint32_t nk,
+                                             uint32_t rt, uint32_t i_, size_t Qpad, size_t q) {
+    const uint4* a = reinterpret_cast<const uint4*>(Ai8) + (tile * nk * 4) * 128 + rt * 32 + i_;  // + c * 128, c = ks * 4 + kg
+    const uint4* b = reinterpret_cast<const uint4*>(Bq) + Qpad + q;                                  // + c * 2 * Qpad (limb 1)
+    int32_t acc = 0;
+    const uint32_t nchunks = nk * 4;
+#pragma unroll 4
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        const uint4 x = a[(size_t)c * 128], y = b[(size_t)c * 2 * Qpad];
+        acc = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, acc, false);
+        acc = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, acc, false);
+    }
+    return acc;
+}
+
+// MODE 0: fused top-k filter. MODE 1: dump the dense approximate score matrix (layout test; computes every low limb).
+template <int R, int MODE>
+__global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
+    const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
+    uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ qc, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
+    uint32_t KP, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    constexpr int kEpiTgWait = 5 * (kI8Stages - 3) + 4 + 5;
+    constexpr int S = kI8hS;
+    __shared__ GemmI8hLds s;
+    constexpr uint32_t cap = 64 * R;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7, lb = b >> 3, groups = nqt / qtg;
+    const uint32_t qt = (xcd % groups) * qtg + lb % qtg;
+    const uint32_t slice = (lb / qtg) * (8 / groups) + xcd / groups;
+    const size_t q0 = (size_t)qt * kI8hBQ;
+    uint32_t t0 = slice * tiles_per_slice, t1 = t0 + tiles_per_slice;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 > t1) t0 = t1;
+    const uint32_t total = (t1 - t0) * nk;
+
+    s.cnt[threadIdx.x] = 0;  // kI8hBQ == threads
+    s.thr[threadIdx.x] = 0;
+    uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
+
+    i32x16_t acc[4][2];  // [row tile][query column tile]: the HIGH limb's sums
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[rt][ct][g] = 0;
+
+    const int half = lane >> 5, C = lane & 31;
+    // this lane's two queries inside the block tile: 64 w + 32 ct + C (lanes l and l + 32 share them)
+    float Aj[2], Bj[2], invAj[2];
+    int32_t lob[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const size_t q = q0 + 64 * w + 32 * ct + C;
+        Aj[ct] = qc[q];
+        Bj[ct] = qc[Qpad + q];
+        invAj[ct] = qc[2 * Qpad + q];
+        lob[ct] = __float_as_int(qc[4 * Qpad + q]);
+    }
+
+    const char* sa = Ai8 + (size_t)t0 * nk * kI8StageBytes + (size_t)wu * 1024;
+    const uint32_t va = (uint32_t)lane * 16u;
+    const uint32_t lds0 = lds_addr_uniform(&s.A[0]) + (uint32_t)wu * 1024u;
+    // Bq[ks][kg][limb][Qpad][16]: depth m of a lane half h is kg = 2 m + h; only limb 0 feeds the matrix pipe
+    const size_t b_step = (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_ct = 32 * 16;
+    const char* sb = Bq + (q0 + (size_t)wu * 64) * 16;
+    const uint32_t vb = ((uint32_t)half * 2u * (uint32_t)Qpad + (uint32_t)C) * 16u;
+    uint32_t a_issued = 0, b_ks = 0;
+    const uint32_t last = total ? total - 1 : 0;
+    auto issue_a = [&]() {
+        const uint32_t st = a_issued < total ? a_issued : last;
+        glds16(uniform_ptr(sa + (size_t)st * kI8StageBytes), va, lds0 + (a_issued % kI8Stages) * kI8StageBytes);
+        ++a_issued;
+    };
+    auto issue_b = [&](u32x4_t& d0, u32x4_t& d1, int m) {
+        const char* p = uniform_ptr(sb + (size_t)b_ks * b_step + (size_t)m * b_depth);
+        gload4(d0, p, vb);
+        gload4(d1, uniform_ptr(p + b_ct), vb);
+    };
+    u32x4_t breg[kI8Lead][4];  // [step % kI8Lead][2 m + ct]
+#pragma unroll
+    for (int r = 0; r < kI8Lead; ++r)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) breg[r][x] = u32x4_t{0u, 0u, 0u, 0u};
+    if (total) {
+        for (int i = 0; i < kI8Stages - 2; ++i) issue_a();
+#pragma unroll
+        for (int r = 0; r < kI8Lead; ++r) {
+            issue_b(breg[r][0], breg[r][1], 0);
+            issue_b(breg[r][2], breg[r][3], 1);
+            b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
+        }
+    }
+    wait_all();
+#pragma unroll
+    for (int r = 0; r < kI8Lead; ++r) {
+        use_after<0>(breg[r][0], breg[r][1]);
+        use_after<0>(breg[r][2], breg[r][3]);
+    }
+    __syncthreads();
+
+    uint32_t tg_next[2] = {0u, 0u};
+    if (MODE == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
+    }
+    uint32_t tile = t0, ks = 0;
+    for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
+#pragma unroll
+        for (int r = 0; r < kI8Lead; ++r) {
+            const uint32_t step = step0 + r;
+            const char* stage = s.A + (step % kI8Stages) * kI8StageBytes;
+            issue_a();
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                i32x4_t a[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    a[rt] = *reinterpret_cast<const i32x4_t*>(stage + ((2 * m + half) * 128 + rt * 32 + C) * 16);
+                constexpr int kYounger = 5 * kI8Lead - 2;
+                if (m == 0) use_after<kYounger>(breg[r][0], breg[r][1]);
+                else use_after<kYounger>(breg[r][2], breg[r][3]);
+                const i32x4_t b0 = __builtin_bit_cast(i32x4_t, breg[r][2 * m]), b1 = __builtin_bit_cast(i32x4_t, breg[r][2 * m + 1]);
+                if (r == 0 && m == 0 && ks == 0) {  // a tile's first MFMAs: C = 0 (no accumulator reset per tile)
+                    const i32x16_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], b0, zero, 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], b1, zero, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        acc[rt][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], b0, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rt], b1, acc[rt][1], 0, 0, 0);
+                    }
+                }
+                issue_b(breg[r][2 * m], breg[r][2 * m + 1], m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            b_ks = (b_ks + 1 == nk) ? 0 : b_ks + 1;
+            if (r == kI8Lead - 1 && ks + 1 == nk) {
+                // ---------------- epilogue for corpus tile `tile`: two queries per lane, 64 corpus rows each ----------------
+                const size_t tb = (size_t)tile * 128;
+                if (MODE == 1) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const size_t q = q0 + 64 * w + 32 * ct + C;
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) {
+                                const uint32_t i_ = (uint32_t)((g & 3) + 8 * (g >> 2) + 4 * half);
+                                const size_t i = tb + 4 * i_ + rt;
+                                const int32_t lo = i8_lo_dot(Ai8, Bq, tile, nk, (uint32_t)rt, i_, Qpad, q);
+                                const int32_t V = (int32_t)(((uint32_t)acc[rt][ct][g] << S) + (uint32_t)lo);
+                                dump[q * ld_dump + i] = __builtin_fmaf(Aj[ct], (float)V, Bj[ct]);
+                            }
+                    }
+                } else {
+                    use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
+                    uint32_t thr[2];
+                    int32_t Tint[2], Thi[2];
+                    float thr_f[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const uint32_t tl = __hip_atomic_load(&s.thr[64 * w + 32 * ct + C], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        thr[ct] = tl > tg_next[ct] ? tl : tg_next[ct];
+                        thr_f[ct] = ord_f32(thr[ct]);
+                        // approx >= thr  =>  V >= Tint (conservative float -> integer, as in gemm_i8_filter_kernel)
+                        //               =>  (hi << S) >= Tint - LOB  =>  hi >= floor((Tint - LOB) / 2^S)
+                        Tint[ct] = INT32_MIN;
+                        Thi[ct] = INT32_MIN;
+                        if (thr[ct] != 0u) {
+                            const float x = (thr_f[ct] - Bj[ct]) * invAj[ct];
+                            if (x >= 2.0e9f || thr[ct] == 0xFFFFFFFFu) {
+                                Tint[ct] = INT32_MAX;
+                                Thi[ct] = INT32_MAX;
+                            } else if (x > -2.0e9f) {
+                                Tint[ct] = (int32_t)__builtin_floorf(x) - 2 - (int32_t)(fabsf(x) * 4.8e-7f);
+                                const long long d = (long long)Tint[ct] - (long long)lob[ct];
+                                Thi[ct] = d < -2147483000ll ? INT32_MIN : (int32_t)(d >> S);
+                            }
+                        }
+                    }
+                    // fast reject on the high limb: one maximum per group of 16 consecutive corpus rows and query column
+                    int32_t gbest[2][4];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            int32_t m4 = INT32_MIN;
+#pragma unroll
+                            for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                                for (int rt = 0; rt < 4; ++rt) m4 = m4 > acc[rt][ct][4 * gq + g3] ? m4 : acc[rt][ct][4 * gq + g3];
+                            gbest[ct][gq] = m4;
+                        }
+                    bool hit[2];
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        const int32_t b01 = gbest[ct][0] > gbest[ct][1] ? gbest[ct][0] : gbest[ct][1];
+                        const int32_t b23 = gbest[ct][2] > gbest[ct][3] ? gbest[ct][2] : gbest[ct][3];
+                        hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
+                    }
+                    if (__any(hit[0] || hit[1])) {
+                        unsigned long long admitted_by[2] = {0ull, 0ull};
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const int ql = 64 * w + 32 * ct + C;
+                            uint64_t* lq = my_lists + (size_t)ql * cap;
+                            bool admitted = false;
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
+                                if (!__any(ghit)) continue;  // wave-uniform: most visits touch one group of one query column
+                                // Rounds: in round r every lane picks its r-th surviving site of this group (static register
+                                // indices, one compare + select per site), then the picked sites are finished ONE AT A TIME by
+                                // the whole wave: lane c computes chunk c of the low limb's dot (16 dimensions: one 16-byte load
+                                // of the site's corpus row and of the query's low limb, four v_dot4_i32_i8), a wave reduction
+                                // gives lo, the picking lane runs the exact test and the append. One memory round trip per
+                                // survivor instead of a 48-step dependent loop in a single lane -- and one copy of that code
+                                // per group, not per site (inlined per site it spilled the operand ring to scratch).
+                                int taken = 0;
+                                while (true) {
+                                    int32_t sel_hi = 0;
+                                    int sel_site = -1, seen = 0;
+#pragma unroll
+                                    for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                                        for (int rt = 0; rt < 4; ++rt) {
+                                            const int32_t hi = acc[rt][ct][4 * gq + g3];
+                                            const bool surv = ghit && hi >= Thi[ct];
+                                            const bool pick = surv && seen == taken;
+                                            sel_hi = pick ? hi : sel_hi;
+                                            sel_site = pick ? (4 * g3 + rt) : sel_site;
+                                            seen += surv ? 1 : 0;
+                                        }
+                                    unsigned long long mm = __ballot(sel_site >= 0);
+                                    if (!mm) break;
+                                    taken += sel_site >= 0 ? 1 : 0;
+                                    while (mm) {
+                                        const int L = __builtin_ctzll(mm);
+                                        mm &= mm - 1;
+                                        const int32_t hiL = __builtin_amdgcn_readlane(sel_hi, L);
+                                        const uint32_t siteL = (uint32_t)__builtin_amdgcn_readlane(sel_site, L);
+                                        const uint32_t rtL = siteL & 3u, i_L = (siteL >> 2) + 8u * (uint32_t)gq + 4u * (uint32_t)(L >> 5);
+                                        const size_t qL = q0 + 64 * wu + 32 * ct + (L & 31);  // wave-uniform
+                                        const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)tile * nk * 4) * 128 + rtL * 32 + i_L;
+                                        const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + qL;
+                                        int32_t part = 0;
+                                        for (uint32_t c = (uint32_t)lane; c < nk * 4; c += 64) {
+                                            const uint4 x = pa[(size_t)c * 128], y = pb[(size_t)c * 2 * Qpad];
+                                            part = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, part, false);
+                                            part = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, part, false);
+                                            part = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, part, false);
+                                            part = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, part, false);
+                                        }
+#pragma unroll
+                                        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+                                        const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)part);
+                                        if (lane == L && V >= Tint[ct]) {
+                                            const uint32_t o = f32_ord(__builtin_fmaf(Aj[ct], (float)V, Bj[ct]));
+                                            const size_t i = tb + 4 * (size_t)i_L + rtL;
+                                            if (o >= thr[ct] && i < N) {
+                                                admitted = admitted || (((uint32_t)i & (kPubEvery - 1)) == 0);
+                                                cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
+                                                gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            admitted_by[ct] = __ballot(admitted);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            unsigned long long m = admitted_by[ct];
+                            m = (m | (m >> 32)) & 0xffffffffull;
+                            while (m) {
+                                const int L = __builtin_ctzll(m);
+                                m &= m - 1;
+                                const size_t qg = q0 + 64 * wu + 32 * ct + L;  // wave-uniform
+                                gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        unsigned long long need = __ballot(c > cap - kGemmBurst);
+                        while (need) {
+                            const int j = __builtin_ctzll(need);
+                            need &= need - 1;
+                            const int qj = 64 * w + j;
+                            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                            uint32_t t;
+                            const uint32_t keep = wave_compact<R>(my_lists + (size_t)qj * cap, cj, KP, &t);
+                            if (lane == 0) {
+                                s.cnt[qj] = keep;
+                                s.thr[qj] = t;
+                                if (t > __hip_atomic_load(&gthr[q0 + qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                    __hip_atomic_fetch_max(&gthr[q0 + qj], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                if (MODE == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
+                }
+                ks = 0;
+                ++tile;
+            } else {
+                ++ks;
+            }
+            if (r == kI8Lead - 1) {  // one barrier per two K-steps: see gemm_bf16_filter_kernel
+                wait_but_youngest<5 * (kI8Stages - 4) + 4>();
+                __syncthreads();
+            }
+        }
+    }
+    wait_all();
+    __syncthreads();
+    if (MODE == 0) {
+        const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned long long need = __ballot(c > KP);
+        uint32_t mine = c;
+        while (need) {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)(64 * w + j) * cap, cj, KP, &t);
+            if (lane == j) mine = keep;
+        }
+        counts[(size_t)slice * Qpad + q0 + 64 * w + lane] = mine;
     }
 }
 

@@ -80,30 +80,35 @@ def _i8_dense(qc, queries):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     q = np.ascontiguousarray(queries, np.float32)
     nq = q.shape[0]
-    qpad = (nq + 255) // 256 * 256
     out = np.empty((nq, len(qc)), np.float32)
-    qcst = np.empty((4, qpad), np.float32)
+    qcst = np.empty((5, (nq + 511) // 512 * 512), np.float32)  # room for either tile width
     got_pad = C.c_size_t(0)
     _lib.check(fn(qc._h, q.ctypes.data, nq, q.shape[1], out.ctypes.data, qcst.ctypes.data, C.byref(got_pad)))
-    assert got_pad.value == qpad
-    return out, qcst[:, :nq]
+    qpad = got_pad.value
+    assert qpad in ((nq + 255) // 256 * 256, (nq + 511) // 512 * 512)
+    return out, qcst.reshape(-1)[:5 * qpad].reshape(5, qpad)[:, :nq]
 
 
+@pytest.mark.parametrize("two_limb", ["0", "1"])
 @pytest.mark.parametrize("n,dim,nq", [(128, 64, 1), (300, 33, 5), (1000, 128, 70), (1025, 200, 300), (3000, 768, 33)])
-def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq):
-    """The int8 MFMA operand layout and the two-limb arithmetic, checked EXACTLY: with s = max|q| / T and t = round(q / s)
-    (T = 256 R1 + 127, R1 from the dimension), the kernel's V must equal sum_d (c_d - 128) t_d as integers -- asymmetric
+def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq, two_limb, monkeypatch):
+    """The int8 MFMA operand layout and the limb arithmetic, checked EXACTLY: with s = max|q| / T and t = round(q / s)
+    (T = (R1 << S) + 2^(S-1) - 1, R1 from the dimension; S = 6: one limb on the matrix pipe + the exact low limb of
+    v_dot4_i32_i8, S = 8: both limbs on the pipe), the kernel's V must equal sum_d (c_d - 128) t_d as integers -- asymmetric
     corpus and queries catch a transposed accumulator map or a k-order mismatch between the operands -- and its approximate
     score A V + B must stay within the engine's own bound E of the reference's asymmetric dot."""
+    monkeypatch.setenv("INNR_I8_TWO_LIMB", two_limb)
+    shift = 8 if two_limb == "1" else 6
     alpha, offset = 2.0, -1.0
     codes = _codes(n, dim, 21, alpha, offset)
     qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
     qs = oracle.generate_uniform(nq, dim, 22)
     qs[0, :] *= np.float32(1e-3)  # a small-magnitude query: its own scale
-    got, (A, Bc, invA, E) = _i8_dense(qc, qs)
+    got, (A, Bc, invA, E, lob) = _i8_dense(qc, qs)
     tmax = (2 ** 31 - 1) // (dim * 128)
-    r1 = min(127, (tmax - 127) // 256)
-    T = np.float32(256 * r1 + 127)
+    lo_max = 2 ** (shift - 1) - 1
+    r1 = min(127, (tmax - lo_max) >> shift)
+    T = np.float32((r1 << shift) + lo_max)
     a255 = np.float32(alpha) / np.float32(255.0)
     cp = codes.astype(np.int64) - 128
     op = oracle.QParams(alpha, offset)
@@ -113,6 +118,10 @@ def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq):
         t = np.clip(np.rint(qs[j] * (np.float32(1.0) / s)), -T, T).astype(np.int64)
         V = cp @ t  # exact
         assert np.abs(V).max() < 2 ** 31
+        # the low limb's reach the one-limb kernel bounds its fast reject with: LOB >= |sum c' r2| for every row
+        r1v = (t + 2 ** (shift - 1)) >> shift
+        r2v = t - (r1v << shift)
+        assert int(lob[j].view(np.int32)) == 128 * int(np.abs(r2v).sum()) and np.abs(cp @ r2v).max() <= int(lob[j].view(np.int32))
         assert np.float32(a255 * s).view(np.uint32) == A[j].view(np.uint32)
         want = (np.float64(A[j]) * V.astype(np.float64) + np.float64(Bc[j])).astype(np.float32)  # one rounding, like the fma
         ulp = np.spacing(np.abs(want).astype(np.float32))
@@ -120,15 +129,16 @@ def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq):
         exact = np.array([oracle.asymmetric_dot_u8(qs[j], codes[i], op) for i in range(0, n, max(1, n // 64))], np.float32)
         sub = got[j][::max(1, n // 64)]
         assert np.all(np.abs(sub.astype(np.float64) - exact.astype(np.float64)) <= E[j] + 1e-6 * np.abs(exact)), (j, E[j])
-        assert E[j] < 0.01 * (np.abs(exact).max() + 1.0)  # the bound is tiny against the scores (16-bit query values)
+        assert E[j] < 0.02 * (np.abs(exact).max() + 1.0)  # the bound is tiny against the scores (14- / 16-bit query values)
 
 
-@pytest.mark.parametrize("engine_name", ["f32-mfma", "int8-mfma"])
+@pytest.mark.parametrize("engine_name", ["f32-mfma", "int8-mfma", "int8-mfma-two-limbs"])
 @pytest.mark.parametrize("n,dim,nq,k,alpha,offset", [(300, 16, 20, 10, 2.0, -1.0), (10_000, 128, 100, 10, 2.0, -1.0),
                                                      (20_000, 96, 300, 100, 3.5, -0.25), (1030, 768, 17, 16, 2.0, -1.0),
                                                      (70_000, 40, 513, 5, 1.0, 0.0), (5000, 130, 9, 240, 2.0, -1.0)])
-def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_name):
-    engine = {"f32-mfma": innr.KNN_MFMA, "int8-mfma": innr.KNN_MFMA_I8}[engine_name]
+def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_name, monkeypatch):
+    monkeypatch.setenv("INNR_I8_TWO_LIMB", "1" if engine_name == "int8-mfma-two-limbs" else "0")
+    engine = {"f32-mfma": innr.KNN_MFMA, "int8-mfma": innr.KNN_MFMA_I8, "int8-mfma-two-limbs": innr.KNN_MFMA_I8}[engine_name]
     codes = _codes(n, dim, 4, alpha, offset)
     qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
     qs = oracle.generate_uniform(nq, dim, 78)

@@ -2,7 +2,9 @@
 
     python tools/bench_u8.py [N] [engine: i8 | f32]
 
-i8  = INNR_KNN_MFMA_I8: int8-MFMA filter (two int8 limbs per query value) + exact f32 re-score and proof
+i8  = INNR_KNN_MFMA_I8: int8-MFMA filter (query = 14-bit fixed point: the high int8 limb on the matrix pipe, the low limb
+      bounded in the fast reject and computed exactly for the survivors) + exact f32 re-score and proof
+      (INNR_I8_TWO_LIMB=1: both limbs of a 16-bit value on the matrix pipe, twice the executed MFMA work)
 f32 = INNR_KNN_MFMA: the codes widened to f32 on the f32 MFMA pipe ("path B")
 Roofline: algorithmic ops 2*Q*N*D against the dense int8 MFMA peak (2x the bf16 one: v_mfma_i32_32x32x32_i8 takes the
 cycles of v_mfma_f32_32x32x16_bf16 at twice the K -- MI355X_MICROARCH.md, Matrix cores) resp. the f32 MFMA peak.
@@ -40,15 +42,16 @@ st1 = KnnStats()
 i1, s1 = qc.knn_multi(qs[:4], k, engine=KNN_EXACT, stats=st1)
 assert np.array_equal(i1, idx[:4]) and np.array_equal(s1.view(np.uint32), sc[:4].view(np.uint32))
 peak = PEAK_I8_TOPS if which == "i8" else PEAK_F32_TFLOPS
+two = os.environ.get("INNR_I8_TWO_LIMB", "0") not in ("", "0")
 print(json.dumps({"workload": f"batch_knn_u8 {n}x{dim} u8, {nq} queries, k={k}",
-                  "engine": "int8 MFMA filter, 2 limbs (v_mfma_i32_32x32x32_i8) + exact f32 re-score + proof" if which == "i8"
-                            else "f32 MFMA on widened u8 codes (path B)",
+                  "engine": ("int8 MFMA filter (v_mfma_i32_32x32x32_i8), " + ("both limbs on the pipe" if two else "high limb on the pipe, exact low limb for survivors")
+                             + " + exact f32 re-score + proof") if which == "i8" else "f32 MFMA on widened u8 codes (path B)",
                   "total_ms": best.total_ms, "gemm_ms": best.gemm_ms, "vectors_per_s": nq * n / (best.total_ms * 1e-3),
                   "qps": nq / (best.total_ms * 1e-3),
-                  "roofline": {"bound": "mfma", "kernel": "gemm_i8_filter_kernel" if which == "i8" else "gemm_filter_kernel<kGemmU8>",
+                  "roofline": {"bound": "mfma", "kernel": ("gemm_i8_filter_kernel" if two else "gemm_i8h_filter_kernel") if which == "i8" else "gemm_filter_kernel<kGemmU8>",
                                "achieved": ops / (best.gemm_ms * 1e-3) / 1e12, "peak": peak, "unit": "TOP/s" if which == "i8" else "TFLOP/s",
                                "frac": ops / (best.gemm_ms * 1e-3) / 1e12 / peak, "algorithmic_ops_per_launch": ops,
-                               "executed_ops_per_launch": ops * (2 if which == "i8" else 1)},
+                               "executed_ops_per_launch": ops * (2 if (which == "i8" and two) else 1)},
                   "corpus_GB": n * dim / 1e9, "queries_fallback": best.queries_fallback, "candidates_kept": best.candidates_kept,
                   "exact_engine_4q_ms": st1.total_ms, "exact_engine_GBps": n * dim / (st1.total_ms * 1e-3) / 1e9,
                   "parity": "filter engine == exact engine on 4 queries (bitwise)"}))

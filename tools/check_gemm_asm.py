@@ -24,7 +24,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
 s = open(path).read()
-KERNELS = r"(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel|21gemm_i8_filter_kernel)"
+KERNELS = r"(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel|21gemm_i8_filter_kernel|22gemm_i8h_filter_kernel)"
 names = [n for n in re.findall(r"^(_ZN4innr" + KERNELS + r"\S+):", s, flags=re.M) if not n.endswith(".kd")]
 if not names:
     sys.exit("no gemm_filter_kernel in " + path)
@@ -101,6 +101,7 @@ for name in names:
     short = re.sub(r".*gemm_filter_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"<\1,\2,\3,\4>", name)
     short = re.sub(r".*gemm_bf16_filter_kernelILi(\d+)ELi(\d+)E.*", r"bf16<\1,\2>", short)
     short = re.sub(r".*gemm_i8_filter_kernelILi(\d+)ELi(\d+)E.*", r"i8<\1,\2>", short)
+    short = re.sub(r".*gemm_i8h_filter_kernelILi(\d+)ELi(\d+)E.*", r"i8h<\1,\2>", short)
     want_pairs = 8  # f32: 8 k-pairs of one K-step; bf16 / int8: 2 ring positions x 2 depths x 2 fragments
     status = "ok" if (len(pairs) == want_pairs and not bad and not unsafe) else "FAIL"
     print(f"{short}: {len(pairs)} operand pairs, {len(bad)} foreign reads, {len(unsafe)} asm loads without s_mov_b64 base  {status}")

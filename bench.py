@@ -121,7 +121,7 @@ def main() -> None:
                          "generate_embedding(dim, i), query j = generate_embedding(dim, N + j)), a one-parameter family with "
                          "hundreds of vectors within the f32 error bound of every k-th score -- the adversarial row: every "
                          "margin proof fails and every query is redone on the exact engine, 8 per corpus pass")
-    ap.add_argument("--engine", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--engine", choices=["f32", "bf16", "i8"], default="f32",
                     help="f32: the MFMA GEMM filter on the f32 pipe (default, the judged configuration); bf16: the same "
                          "pipeline with the filter on the bf16 pipe (INNR_KNN_MFMA_BF16) -- identical results, reported "
                          "as a side measurement with its own roofline")
@@ -155,12 +155,12 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from innr_amd import KNN_MFMA, KNN_MFMA_BF16, METRIC_COSINE, METRIC_DOT, Context, KnnStats
+    from innr_amd import KNN_MFMA, KNN_MFMA_BF16, KNN_MFMA_I8, METRIC_COSINE, METRIC_DOT, Context, KnnStats
     from innr_amd import batch as B
     from innr_amd.dist import Comm, ShardedKnn
 
     metric = METRIC_DOT if args.metric == "dot" else METRIC_COSINE
-    engine = KNN_MFMA_BF16 if args.engine == "bf16" else KNN_MFMA
+    engine = {"bf16": KNN_MFMA_BF16, "i8": KNN_MFMA_I8}.get(args.engine, KNN_MFMA)
     ctx = Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream for the kernels and the collective
     n_total = args.n_per_gpu * world
@@ -257,9 +257,11 @@ def main() -> None:
             "config": {
                 "workload": f"batch_knn_{args.metric} f32, {args.n_per_gpu}x{args.dim} corpus per GPU "
                             f"({n_total} total), {args.queries}-query batch, k={args.k}",
-                "engine": "f32 MFMA GEMM + fused top-k filter + exact re-score" if args.engine == "f32" else
-                          "bf16 MFMA GEMM filter (K-packed bf16 corpus copy) + fused top-k filter + exact f32 re-score "
-                          "and proof: identical results",
+                "engine": {"f32": "f32 MFMA GEMM + fused top-k filter + exact re-score",
+                           "bf16": "bf16 MFMA GEMM filter (K-packed bf16 corpus copy) + fused top-k filter + exact f32 re-score "
+                                   "and proof: identical results",
+                           "i8": "int8 MFMA GEMM filter (scalar-quantised K-packed corpus copy, 14-bit queries) + fused top-k filter + "
+                                 "exact f32 re-score and proof: identical results"}[args.engine],
                 "candidates_per_query": int(kept),
                 "queries_redone_exactly_per_step": float(np.mean(fallbacks)),
                 "parallelism": f"range-partitioned corpus x{world}, all-gather of per-shard top-k" if world > 1 else "1 GPU",
@@ -267,38 +269,41 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "gemm_filter_kernel (v_mfma_f32_32x32x2_f32)" if args.engine == "f32"
-                          else "gemm_bf16_filter_kernel (v_mfma_f32_32x32x16_bf16)",
+                "kernel": {"f32": "gemm_filter_kernel (v_mfma_f32_32x32x2_f32)", "bf16": "gemm_bf16_filter_kernel (v_mfma_f32_32x32x16_bf16)",
+                           "i8": "gemm_i8h_filter_kernel (v_mfma_i32_32x32x32_i8)"}[args.engine],
                 "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS if args.engine == "f32" else PEAK_BF16_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / (PEAK_F32_MFMA_TFLOPS if args.engine == "f32" else PEAK_BF16_MFMA_TFLOPS),
+                "peak": {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "i8": 2 * PEAK_BF16_MFMA_TFLOPS}[args.engine],
+                "unit": "TFLOP/s" if args.engine != "i8" else "TOP/s",
+                "frac": achieved / {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "i8": 2 * PEAK_BF16_MFMA_TFLOPS}[args.engine],
                 "kernel_ms": g_ms,
                 "algorithmic_flop_per_launch": flop,
                 **(pmc_traffic(args) if args.engine == "f32" else {"traffic": None}),
             },
         }
         if world == 1 and args.engine == "f32" and args.data == "uniform" and not args.no_side_rows:
-            # side row (not `value`): the same call with the filter stage on the bf16 matrix pipe -- INNR_KNN_MFMA_BF16, what
-            # INNR_KNN_AUTO picks for such a batch -- and a check that it returns the f32 engine's answer bit for bit
+            # side rows (not `value`): the same call with the FILTER stage on a low-precision matrix pipe -- the bf16 copy
+            # (INNR_KNN_MFMA_BF16, what INNR_KNN_AUTO picks for such a batch) and the scalar-quantised int8 copy
+            # (INNR_KNN_MFMA_I8) -- each with a check that it returns the f32 engine's answer bit for bit
             f_idx, f_sc = idx.clone(), sc.clone()
-            bl = _gpu_local_search(vb, metric, KNN_MFMA_BF16)
-            st2 = KnnStats()
-            bl(q_dev, args.k, st2)  # builds the K-packed bf16 corpus copy
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for key, eng, kname, peak in (("bf16_filter_engine", KNN_MFMA_BF16, "gemm_bf16_filter_kernel (v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS),
+                                          ("int8_filter_engine", KNN_MFMA_I8, "gemm_i8h_filter_kernel (v_mfma_i32_32x32x32_i8)", 2 * PEAK_BF16_MFMA_TFLOPS)):
+                bl = _gpu_local_search(vb, metric, eng)
                 st2 = KnnStats()
-                b_idx, b_sc = bl(q_dev, args.k, st2)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / args.steps
-            out["bf16_filter_engine"] = {
-                "ms_per_step": dt2 * 1e3, "value": args.queries * n_total / dt2, "unit": "vectors/s", "kernel_ms": st2.gemm_ms,
-                "kernel": "gemm_bf16_filter_kernel (v_mfma_f32_32x32x16_bf16)",
-                "kernel_frac_of_bf16_peak": flop / (st2.gemm_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if st2.gemm_ms > 0 else None,
-                "queries_redone": int(st2.queries_fallback), "candidates_per_query": int(st2.candidates_kept),
-                "identical_to_f32_engine": bool(torch.equal(f_idx, b_idx) and torch.equal(f_sc.view(torch.int32), b_sc.view(torch.int32))),
-            }
+                bl(q_dev, args.k, st2)  # builds the K-packed corpus copy
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    st2 = KnnStats()
+                    b_idx, b_sc = bl(q_dev, args.k, st2)
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t1) / args.steps
+                out[key] = {
+                    "ms_per_step": dt2 * 1e3, "value": args.queries * n_total / dt2, "unit": "vectors/s", "kernel_ms": st2.gemm_ms,
+                    "kernel": kname, "engine_ran": int(st2.engine),
+                    "kernel_frac_of_pipe_peak": flop / (st2.gemm_ms * 1e-3) / 1e12 / peak if st2.gemm_ms > 0 else None,
+                    "queries_redone": int(st2.queries_fallback), "candidates_per_query": int(st2.candidates_kept),
+                    "identical_to_f32_engine": bool(torch.equal(f_idx, b_idx) and torch.equal(f_sc.view(torch.int32), b_sc.view(torch.int32))),
+                }
         if args.data == "lcg":
             # every proof fails on this data: the step is the GEMM pass + ceil(redone / 8) exact corpus passes (HBM-bound)
             nredo = float(np.mean(fallbacks))

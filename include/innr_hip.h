@@ -55,12 +55,17 @@ typedef int innr_status;
                               * bf16 error bound, unproven queries are redone exactly. Dot metric with k <= 48; every other
                               * call is served by INNR_KNN_MFMA (innr_knn_stats.engine tells). Not chosen by INNR_KNN_AUTO. */
 
-#define INNR_KNN_MFMA_I8 4 /* innr_batch_knn_u8[_dev] only: the filter on the INTEGER matrix pipe (v_mfma_i32_32x32x32_i8, 32x the f32
-                            * MFMA rate) over a K-packed signed copy of the codes built on first use (+ N*D bytes of HBM), the f32
-                            * query as two int8 limbs of a 16-bit fixed-point value. Results unchanged: candidates are re-scored in
-                            * the reference's f32 order and proven against the quantisation bound, unproven queries redone exactly.
-                            * Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call (stats->engine tells).
-                            * INNR_KNN_AUTO picks it for query batches on large code corpora. */
+#define INNR_KNN_MFMA_I8 4 /* the filter on the INTEGER matrix pipe (v_mfma_i32_32x32x32_i8: twice the bf16 MFMA rate, 32x the f32 one).
+                            * innr_batch_knn_u8[_dev]: over a K-packed signed copy of the codes built on first use (+ N*D bytes of
+                            * HBM), the f32 query as a 14-bit fixed-point value -- its high int8 limb on the matrix pipe, the low
+                            * limb bounded in the filter and computed exactly for the survivors (lists of 256: a 16-bit value, both
+                            * limbs on the pipe). Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call.
+                            * INNR_KNN_AUTO picks it for query batches on large code corpora.
+                            * innr_batch_knn[_dev] on an F32 batch (dot, cosine; k <= 48): the corpus scalar-quantised once with a
+                            * single (offset, alpha) -- quantize_u8 with the corpus' own range, the first stage of the two-stage
+                            * pipeline of scalar.rs:366-368 -- filtered on the integer pipe, re-scored on the f32 corpus and
+                            * PROVEN against (alpha / 510) |q|_1 + the query's quantisation; unproven queries redone on the f32
+                            * engine. Results unchanged in every case (stats->engine tells which engine ran). */
 
 #define INNR_MAX_K 240 /* largest k the candidate-list engines hold (k + margin <= 256). Every kNN entry point accepts
                         * any k, like the reference: beyond INNR_MAX_K innr_batch_knn[_dev], innr_batch_knn_u8[_dev],

@@ -114,6 +114,7 @@ struct innr_ctx {
     struct RedoBufs {
         DevBuf q, idx, sc, map, qn;
     } redo[2];  // unproven queries, gathered and redone as ONE batch; [1]: the batch's own unproven queries (redo_batch)
+    DevBuf q_hat;      // int8 filter of an f32 corpus, cosine: the normalised queries
     DevBuf q_pad;      // exact engine: a ragged tail of 2-3 / 5-7 queries padded with zero rows to a 4- / 8-query pass
     DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
     DevBuf sort_keys;  // [2][N] composites: unsorted, sorted
@@ -182,6 +183,11 @@ struct innr_batch {
     // int8 filter engine (kernels_gemm_i8.h): K-packed signed copy of the u8 codes, built on first use, always owned
     char* Ai8 = nullptr;
     uint32_t ai8_nk = 0;
+    // ... and of an F32 batch: its values scalar-quantised with one (offset, alpha) for the whole corpus (Ai8, i8_*), resp. its
+    // normalised rows quantised over [-1, 1] (Ai8n: the cosine filter) -- INNR_KNN_MFMA_I8 on an f32 batch
+    char* Ai8n = nullptr;
+    float i8_alpha = 0.0f, i8_offset = 0.0f, i8n_alpha = 0.0f, i8n_offset = 0.0f;
+    bool i8_weak = false, i8n_weak = false;  // most proofs failed on this corpus (a range blown up by outliers): AUTO stops picking the filter
 };
 
 namespace innr {
@@ -936,7 +942,7 @@ void innr_ctx_destroy(innr_ctx* c) {
     (void)ctx_sync(c);
     DevBuf* bufs[] = {&c->gthr, &c->sel_tmp[0], &c->sel_tmp[1], &c->selcnt_tmp[0], &c->selcnt_tmp[1],
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
-                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad,
+                      &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad, &c->q_hat,
                       &c->redo[0].q, &c->redo[0].idx, &c->redo[0].sc, &c->redo[0].map, &c->redo[0].qn,
                       &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn};
     for (DevBuf* b : bufs) b->release();
@@ -1077,6 +1083,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->Ab) (void)hipFree(b->Ab);
     if (b->Abn) (void)hipFree(b->Abn);
     if (b->Ai8) (void)hipFree(b->Ai8);
+    if (b->Ai8n) (void)hipFree(b->Ai8n);
     delete b;
 }
 
@@ -1435,6 +1442,12 @@ static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, siz
     return INNR_OK;
 }
 
+// the int8 filter in front of an f32 corpus (defined with the int8 engine further down)
+static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout);
+static size_t f32_i8_copy_bytes(const innr_batch* b);
+static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
+                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served);
+
 extern "C" {
 
 // ---- kNN -----------------------------------------------------------------------------------------------
@@ -1464,19 +1477,25 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) {
         engine = innr_batch_auto_engine(b, Q);
-        // The bf16 filter (identical results, ~6x the f32 engine's rate at C2) when it applies -- dot / cosine, k <= 48, a
-        // batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
-        // everything else with room to spare (the copy is N*D*2 bytes and is kept for the batch's lifetime).
+        // A low-precision FILTER (identical results; 6-7x the f32 engine's rate at C2) when one applies -- dot / cosine, k <= 48,
+        // a batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
+        // everything else with room to spare (copies are kept for the batch's lifetime): the int8 one first (N*D bytes, the
+        // faster kernel), else the bf16 one (N*D*2 bytes).
         if (engine == INNR_KNN_MFMA && Q >= 128 && metric != INNR_METRIC_L2SQ && pick_kp(4 * kout + 64, 0) <= 256 &&
             !getenv("INNR_NO_AUTO_BF16")) {
-            const bool have = metric == INNR_METRIC_COSINE ? b->Abn != nullptr : b->Ab != nullptr;
+            const bool cosm = metric == INNR_METRIC_COSINE;
             size_t free_b = 0, total_b = 0;
-            if (have || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * bf16_copy_bytes(b) + ((size_t)8 << 30)))
+            const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+            const size_t slack = (size_t)8 << 30;
+            if (f32_i8_eligible(b, metric, Q, kout) && !getenv("INNR_NO_AUTO_I8") && !(cosm ? b->i8n_weak : b->i8_weak) &&
+                ((cosm ? b->Ai8n : b->Ai8) != nullptr || (have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
+                engine = INNR_KNN_MFMA_I8;
+            else if ((cosm ? b->Abn : b->Ab) != nullptr || (have_mem && free_b > 2 * bf16_copy_bytes(b) + slack))
                 engine = INNR_KNN_MFMA_BF16;
         }
     }
-    if (engine == INNR_KNN_MFMA_I8) engine = INNR_KNN_MFMA;  // the int8 filter is the code corpora's (innr_batch_knn_u8)
-    if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
+    if (engine == INNR_KNN_MFMA_I8 && !f32_i8_eligible(b, metric, Q, kout)) engine = INNR_KNN_MFMA;  // squared L2, k > 48, a view ...
+    if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16 || engine == INNR_KNN_MFMA_I8) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     INNR_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
@@ -1491,7 +1510,13 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     }
     uint32_t nfallback = 0, kept = 0;
     float gemm_ms = 0.0f;
-    if (engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) {
+    if (engine == INNR_KNN_MFMA_I8) {
+        bool served = false;
+        INNR_TRY(knn_f32_i8(b, metric, d_queries, Q, kout, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms, &served));
+        if (!served) engine = INNR_KNN_MFMA;  // a constant or non-finite corpus: nothing to quantise against
+    }
+    if (engine == INNR_KNN_MFMA_I8) {
+    } else if (engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16) {
         INNR_TRY(knn_mfma(b, metric, d_queries, Q, kout, dQn, d_out_idx, d_out_score, &nfallback, &kept, &gemm_ms,
                           engine == INNR_KNN_MFMA_BF16));
         if (gemm_ms < 0.0f) {  // not a dot-kind call / k too large / degenerate norms: the f32 engine served it
@@ -2040,13 +2065,13 @@ struct I8Plan {
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
     bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
 };
-static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
+static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0) {
     I8Plan p;
-    p.two = i8_two_limb(kout);
+    p.two = i8_two_limb(kout) || kp_override > 128;
     const size_t bq = p.two ? (size_t)kI8BQ : (size_t)kI8hBQ;  // queries per block tile
     p.Qpad = round_up(Q, bq);
     p.nqt = (uint32_t)(p.Qpad / bq);
-    p.KP = pick_kp(kout, 16);
+    p.KP = kp_override ? kp_override : pick_kp(kout, 16);
     p.cap = (uint32_t)cand_cap((int)p.KP);
     p.ntiles = (uint32_t)(b->ldN / 128);
     const uint32_t target = std::max(1u, (uint32_t)b->ctx->num_cus / p.nqt);  // one 8-wave block per CU
@@ -2066,7 +2091,8 @@ static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout) {
 
 template <int MODE>
 static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q, const float* qc, float* dump, size_t ld_dump,
-                                  const uint32_t* seed = nullptr) {
+                                  const uint32_t* seed = nullptr, const char* corpus = nullptr) {
+    if (!corpus) corpus = b->Ai8;
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
     const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
@@ -2077,7 +2103,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
     const bool two = p.two;
 #define INNR_I8_ARGS                                                                                                      \
-    b->Ai8, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
+    corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
         c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump
 #define INNR_I8_LAUNCH(RR)                                                                                                \
     do {                                                                                                                  \
@@ -2102,14 +2128,16 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     return INNR_OK;
 }
 
-// queries -> two int8 limbs + per-query constants: Bq in c->q_bf16, qc[4][Qpad] at c->misc
-static innr_status prep_queries_i8(innr_batch* b, const I8Plan& p, const float* dQ, size_t Q, const float* qsum) {
+// queries -> two int8 limbs + per-query constants: Bq in c->q_bf16, qc[5][Qpad] at c->misc
+// (alpha, offset: the code corpus' QuantizationParams, or the scalar quantisation of an f32 corpus' filter copy)
+static innr_status prep_queries_i8(innr_batch* b, const I8Plan& p, const float* dQ, size_t Q, const float* qsum, float alpha,
+                                   float offset) {
     innr_ctx* c = b->ctx;
     INNR_TRY(c->q_bf16.ensure((size_t)b->ai8_nk * 8 * p.Qpad * 16));
     INNR_TRY(c->misc.ensure(5 * p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
     pack_queries_i8_kernel<<<(unsigned)p.Qpad, 64, 0, c->stream>>>(dQ, qsum, (uint32_t)Q, (uint32_t)b->D, b->ai8_nk, (uint32_t)p.Qpad,
-                                                                   i8_limb_r1((uint32_t)b->D, i8_shift(p.two)), i8_shift(p.two), b->alpha / 255.0f,
-                                                                   b->offset, reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
+                                                                   i8_limb_r1((uint32_t)b->D, i8_shift(p.two)), i8_shift(p.two), alpha / 255.0f,
+                                                                   offset, reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
 }
@@ -2120,7 +2148,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     innr_ctx* c = b->ctx;
     INNR_TRY(ensure_i8_corpus(b));
     const I8Plan p = plan_i8(b, Q, kout);
-    INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum));
+    INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum, b->alpha, b->offset));
     const float* qc = c->misc.as<float>();
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
@@ -2185,7 +2213,7 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
     INNR_HIP_CHECK(copy_in(c, c->q_row.p, queries, Q * D * sizeof(float)));
     float* qsum = c->q_norm.as<float>();
     query_sums_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(c->q_row.as<float>(), (uint32_t)Q, (uint32_t)D, D, qsum, qsum + p.Qpad);
-    INNR_TRY(prep_queries_i8(b, p, c->q_row.as<float>(), Q, qsum));
+    INNR_TRY(prep_queries_i8(b, p, c->q_row.as<float>(), Q, qsum, b->alpha, b->offset));
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->scores.ensure(p.Qpad * b->ldN * sizeof(float)));
@@ -2195,6 +2223,158 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
     if (qc_out) INNR_HIP_CHECK(hipMemcpyAsync(qc_out, c->misc.p, 5 * p.Qpad * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (qpad_out) *qpad_out = p.Qpad;
     INNR_HIP_CHECK(ctx_sync(c));
+    return INNR_OK;
+}
+
+// ---- the int8 filter in front of an F32 corpus (INNR_KNN_MFMA_I8 on an f32 batch; dot and cosine) ------------------------------
+// The corpus is scalar-quantised once with a single (offset, alpha) -- the reference's own quantize_u8 with the corpus' range,
+// i.e. the first stage of its two-stage pipeline (scalar.rs:366-368) -- and filtered on the integer matrix pipe (twice the bf16
+// rate, half the bytes of the bf16 copy); the candidates are re-scored on the f32 corpus in the reference's order and the answer
+// is PROVEN against bound = query quantisation + (alpha / 510) |q|_1 + the reference's own accumulation error; unproven queries
+// go through the f32 GEMM engine as one batch, like the bf16 filter's.
+static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout) {
+    return b->V && metric != INNR_METRIC_L2SQ && pick_kp(4 * kout + 64, 0) <= 256 && b->D >= 1 && b->D <= 65535 &&
+           i8_limb_r1((uint32_t)b->D, 8) >= 1 && i8_limb_r1((uint32_t)b->D, (uint32_t)kI8hS) >= 1 && b->ldN < ((size_t)1 << 31) &&
+           Q < ((size_t)1 << 24) && b->gemm_ok;
+}
+static size_t f32_i8_copy_bytes(const innr_batch* b) { return (b->ldN / 128) * (size_t)i8_nk(b) * kI8StageBytes; }
+
+static innr_status ensure_f32_i8_corpus(innr_batch* b, bool normalised, bool* usable) {
+    *usable = true;
+    char*& copy = normalised ? b->Ai8n : b->Ai8;
+    if (copy) return INNR_OK;
+    // the range of what is quantised: the corpus values, resp. the normalised rows (for 768-dimensional uniform data these live
+    // in +-0.06: quantising them over [-1, 1] would throw four of the eight bits away)
+    float offset, alpha;
+    {
+        innr_ctx* c = b->ctx;
+        INNR_TRY(c->misc.ensure(4096));
+        INNR_HIP_CHECK(hipMemsetAsync(c->misc.p, 0, 8, c->stream));
+        dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+        minmax_pdx_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, c->misc.as<uint32_t>(),
+                                                       normalised ? b->invn : nullptr);
+        INNR_HIP_CHECK(hipGetLastError());
+        uint32_t k[2] = {0, 0};
+        INNR_HIP_CHECK(copy_out(c, k, c->misc.p, 8));
+        INNR_HIP_CHECK(ctx_sync(c));
+        const float mn = ord_f32(~k[0]), mx = ord_f32(k[1]);
+        alpha = mx - mn;
+        if (!k[0] || !k[1] || !(alpha > 0.0f) || !(alpha - alpha == 0.0f)) {  // empty / constant / infinite range: nothing to quantise against
+            *usable = false;
+            return INNR_OK;
+        }
+        offset = mn;
+        (normalised ? b->i8n_alpha : b->i8_alpha) = alpha;
+        (normalised ? b->i8n_offset : b->i8_offset) = offset;
+    }
+    const uint32_t nk = i8_nk(b);
+    const size_t ntiles = b->ldN / 128, bytes = ntiles * nk * (size_t)kI8StageBytes;
+    hipError_t e = hipMalloc((void**)&copy, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for the int8 filter copy failed: %s", bytes, hipGetErrorString(e));
+        copy = nullptr;
+        return INNR_E_OOM;
+    }
+    const size_t nthreads = ntiles * nk * 128;
+    pack_corpus_f32_i8_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, b->ctx->stream>>>(
+        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk, nthreads, offset, 255.0f / alpha, normalised ? b->invn : nullptr,
+        reinterpret_cast<uint4*>(copy));
+    INNR_HIP_CHECK(hipGetLastError());
+    b->ai8_nk = nk;
+    return INNR_OK;
+}
+
+// *served = false: the engine does not apply to this corpus (constant values): the caller takes the f32 engine
+static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
+                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served) {
+    innr_ctx* c = b->ctx;
+    const bool cos = metric == INNR_METRIC_COSINE;
+    *served = false;
+    INNR_TRY(ensure_norms(b));
+    if (!(b->max_norm - b->max_norm == 0.0f) || !(b->max_norm >= 1e-12f)) return INNR_OK;
+    if (cos) INNR_TRY(ensure_invnorms(b));
+    bool usable = true;
+    INNR_TRY(ensure_f32_i8_corpus(b, cos, &usable));
+    if (!usable) return INNR_OK;
+    *served = true;
+    const float alpha = cos ? b->i8n_alpha : b->i8_alpha, offset = cos ? b->i8n_offset : b->i8_offset;
+    const I8Plan p = plan_i8(b, Q, kout, pick_kp(4 * kout + 64, 0));
+    // exact query norms; cosine: 1/||q|| and the normalised copy the filter multiplies; sum and L1 norm of what it multiplies
+    INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
+    INNR_TRY(c->tmp_norms.ensure(3 * p.Qpad * sizeof(float)));
+    float* qsum = c->tmp_norms.as<float>();
+    float* ql1 = qsum + p.Qpad;
+    float* invq = ql1 + p.Qpad;
+    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    const float* Qp = dQ;
+    if (cos) {
+        INNR_TRY(c->q_hat.ensure(std::max<size_t>(Q * b->D, 1) * sizeof(float)));
+        inv_qnorms_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, Q, invq);
+        INNR_HIP_CHECK(hipGetLastError());
+        Qp = c->q_hat.as<float>();
+    }
+    f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, cos ? invq : nullptr,
+                                                                            cos ? c->q_hat.as<float>() : nullptr, qsum, ql1);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(prep_queries_i8(b, p, Qp, Q, qsum, alpha, offset));
+    float* qc = c->misc.as<float>();
+    // the reference's own accumulation against the true dot: (D + 2) u |q||v| (half of the f32 GEMM engine's cdu)
+    const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
+    f32i8_finish_bound_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, c->stream>>>(qc, (uint32_t)p.Qpad, (uint32_t)Q, ql1, c->q_norm.as<float>(),
+                                                                               alpha, cos ? cdu * 1.02f : cdu * b->max_norm, cos ? 1 : 0);
+    INNR_HIP_CHECK(hipGetLastError());
+    const float* eq = qc + 3 * p.Qpad;
+    uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
+    INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+    const uint32_t* seed = nullptr;
+    constexpr size_t kSeedN = 2048;
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
+        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, p.KP, c->seed_idx.as<uint64_t>(),
+                                 c->seed_score.as<float>(), ScanExt(), kSeedN));
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
+        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->seed_score.as<float>(), (uint32_t)Q, p.KP, eq, sd,
+                                                                                       (uint32_t)p.Qpad);
+        INNR_HIP_CHECK(hipGetLastError());
+        seed = sd;
+    }
+    INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
+    INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
+    INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, cos ? b->Ai8n : b->Ai8));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
+#define INNR_RESCORE_EQ(METV, RKV)                                                                                   \
+    rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,           \
+                                                                 c->q_norm.as<float>(), nullptr, c->sel.as<uint64_t>(), \
+                                                                 c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout, 0.0f, \
+                                                                 b->index_base, d_out_idx, d_out_score, fallback, eq)
+    const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
+    if (cos) {
+        if (rk == 1) INNR_RESCORE_EQ(1, 1); else if (rk == 2) INNR_RESCORE_EQ(1, 2); else INNR_RESCORE_EQ(1, 4);
+    } else {
+        if (rk == 1) INNR_RESCORE_EQ(0, 1); else if (rk == 2) INNR_RESCORE_EQ(0, 2); else INNR_RESCORE_EQ(0, 4);
+    }
+#undef INNR_RESCORE_EQ
+    INNR_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> fb(Q);
+    INNR_HIP_CHECK(copy_out(c, fb.data(), fallback, Q * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms = ms;
+    std::vector<uint32_t> redo;
+    for (size_t q = 0; q < Q; ++q)
+        if (fb[q]) redo.push_back((uint32_t)q);
+    *nfallback = (uint32_t)redo.size();
+    *kept = p.KP;
+    if (Q >= 16 && redo.size() * 2 > Q) (cos ? b->i8n_weak : b->i8_weak) = true;  // AUTO takes the bf16 filter on this corpus from now on
+    if (!redo.empty())  // one batch on the f32 GEMM engine (its own proof, the exact engine behind it)
+        INNR_TRY(redo_batch(b, metric, dQ, cos ? c->q_norm.as<float>() : nullptr, redo, kout, d_out_idx, d_out_score,
+                            redo.size() >= 4 ? pick_kp(kout, 16) : 0u, 0));
     return INNR_OK;
 }
 

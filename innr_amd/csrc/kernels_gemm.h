@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
                                                      const uint32_t* __restrict__ sel_cnt, uint32_t KP, uint32_t kout,
                                                      float err_scale, uint64_t index_base,
                                                      uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                     uint32_t* __restrict__ fallback) {
+                                                     uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr) {
     constexpr bool COS = MET == 1, L2 = MET == 2;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
             const float Cq = qaux[q];
             bad = !(exact_k < (Cq - T) - err_scale * Cq);
         } else {
-            const float E = COS ? err_scale : err_scale * qn;
+            const float E = eq ? eq[q] : (COS ? err_scale : err_scale * qn);  // eq: a per-query bound (int8 filter of an f32 corpus)
             bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
         }
     }

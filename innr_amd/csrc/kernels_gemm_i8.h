@@ -83,6 +83,90 @@ __global__ __launch_bounds__(256) void pack_corpus_i8_kernel(const uint8_t* __re
     }
 }
 
+// An f32 PDX corpus as the int8 filter's operand: every value scalar-quantised with ONE (offset, alpha) for the whole corpus --
+// quantize_u8 (scalar.rs:212-225) with the corpus' own range, i.e. the first stage of the two-stage pipeline the reference
+// describes (scalar.rs:366-368), except that here the second stage PROVES the answer: |v_d - (offset + alpha c_d / 255)| <=
+// alpha / 510 for every value inside the range, so the filter's score is within (alpha / 510) sum_d |q_d| of q.v.
+// rowscale (nullable): 1/||v|| per row -- the cosine copy quantises the normalised rows (range [-1, 1]).
+__global__ __launch_bounds__(256) void pack_corpus_f32_i8_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
+                                                                  uint32_t nk, size_t nthreads, float offset, float inv_alpha,
+                                                                  const float* __restrict__ rowscale, uint4* __restrict__ Ai8) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nthreads) return;
+    const uint32_t i = (uint32_t)(t & 31), kg = (uint32_t)((t >> 5) & 3);
+    const size_t tk = t >> 7;  // tile * nk + ks
+    const uint32_t ks = (uint32_t)(tk % nk);
+    const size_t row0 = (tk / nk) * 128 + 4 * (size_t)i;  // < ldN (a multiple of 256)
+    float rs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (rowscale) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rowscale + row0);
+        rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+    }
+    uint32_t w[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const uint32_t d = ks * 64 + kg * 16 + e;
+        uint32_t v = 0x80808080u;  // code 128 -> c' = 0: padding dimensions contribute nothing
+        if (d < D) {
+            const float4 x = *reinterpret_cast<const float4*>(V + (size_t)d * ldN + row0);
+            v = (uint32_t)quantize_one(x.x * rs[0], offset, inv_alpha) | ((uint32_t)quantize_one(x.y * rs[1], offset, inv_alpha) << 8) |
+                ((uint32_t)quantize_one(x.z * rs[2], offset, inv_alpha) << 16) | ((uint32_t)quantize_one(x.w * rs[3], offset, inv_alpha) << 24);
+        }
+        w[e] = v ^ 0x80808080u;
+    }
+    uint4* out = Ai8 + (tk * 4 + kg) * 128 + i;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            uint32_t byte = (w[e] >> (8 * rt)) & 0xffu;
+            if (row0 + rt >= N) byte = 0u;
+            o[e >> 2] |= byte << (8 * (e & 3));
+        }
+        out[rt * 32] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// queries of the f32-corpus filter: (cosine: normalised copy,) sum and L1 norm per query
+__global__ void f32i8_query_prep_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, const float* __restrict__ qscale,
+                                        float* __restrict__ qhat, float* __restrict__ qsum, float* __restrict__ ql1) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Q) return;
+    const float sc = qscale ? qscale[j] : 1.0f;
+    float s1 = 0.0f, l1 = 0.0f;
+    for (uint32_t d = 0; d < D; ++d) {
+        const float x = Qm[(size_t)j * D + d] * sc;
+        if (qhat) qhat[(size_t)j * D + d] = x;
+        s1 += x;
+        l1 += fabsf(x);
+    }
+    qsum[j] = s1;
+    ql1[j] = l1 * (1.0f + 1.2e-7f * (float)D);  // an upper bound of the true L1 norm despite the rounding of the sum
+}
+
+// the proof's bound per query: the int8 engine's own share (qc[3]: the query's quantisation, float rounding) + the corpus
+// quantisation (alpha / 510 per value, clamp slack) + the reference's own f32 accumulation against the true dot
+__global__ void f32i8_finish_bound_kernel(float* __restrict__ qc, uint32_t Qpad, uint32_t Q, const float* __restrict__ ql1,
+                                          const float* __restrict__ qnorm, float alpha, float ref_scale, int cosine) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Q) return;
+    const float ref = cosine ? ref_scale : ref_scale * qnorm[j];
+    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + (alpha / 510.0f) * 1.002f * ql1[j] + ref) * 1.0001f;
+}
+
+__global__ void seed_thresholds_eq_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
+                                          const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Qpad) return;
+    uint32_t o = 0;
+    if (j < Q) {
+        const float t = kth_scores[(size_t)j * KP + KP - 1] - eq[j] * 1.0001f - 1e-30f;
+        if (t - t == 0.0f) o = f32_ord(t);
+    }
+    seed[j] = o;
+}
+
 // One wave per query: scale, two limbs per dimension, per-query constants.
 //   qc[0][j] = A_j, qc[1][j] = B_j, qc[2][j] = 1 / A_j, qc[3][j] = the query's share of the proof's error bound:
 //   |approx - (alpha/255 * true mixed dot + offset * sum q)| <= |alpha/255| s_j 64 D (quantisation, sum|c'| <= 128 D) + float

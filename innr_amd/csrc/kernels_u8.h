@@ -89,14 +89,17 @@ __global__ __launch_bounds__(256) void quantize_pdx_kernel(const float* __restri
 // reference's comparisons are false for NaN). Keys: f32_ord (total order), so -0.0 < +0.0 -- the reference keeps
 // whichever zero it met first, the one point where a parallel reduction cannot follow a sequential scan.
 // out[0] = max over values of ~ord (i.e. min), out[1] = max of ord; both start at 0 = "nothing seen".
+// rowscale (nullable): the range of V[d][i] * rowscale[i] (the normalised rows: the cosine copy of the int8 filter)
 __global__ __launch_bounds__(256) void minmax_pdx_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
-                                                          uint32_t* __restrict__ out) {
+                                                          uint32_t* __restrict__ out, const float* __restrict__ rowscale = nullptr) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     uint32_t kmin = 0, kmax = 0;
     if (i4 < ldN) {
+        float4 rs = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (rowscale) rs = *reinterpret_cast<const float4*>(rowscale + i4);
         for (uint32_t d = blockIdx.y; d < D; d += gridDim.y) {
             const float4 v = *reinterpret_cast<const float4*>(V + (size_t)d * ldN + i4);
-            const float x[4] = {v.x, v.y, v.z, v.w};
+            const float x[4] = {v.x * rs.x, v.y * rs.y, v.z * rs.z, v.w * rs.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (i4 + c < N && x[c] == x[c]) {

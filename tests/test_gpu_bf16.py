@@ -14,16 +14,18 @@ from test_gpu_exact import B, _check_knn, _corpus, _queries, bits_equal, innr, s
 
 @pytest.mark.parametrize("n,dim,nq,k", [(10_000, 128, 100, 10), (20_000, 100, 513, 10), (70_000, 64, 600, 10), (3000, 20, 300, 48),
                                         (257, 33, 5, 16), (1000, 64, 9, 33), (5, 3, 2, 10), (200_000, 32, 40, 1)])
-def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k):
+@pytest.mark.parametrize("filt", ["bf16", "int8"])
+def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k, filt):
     rows, data = _corpus(n, dim, 77, uniform=True)
     rows = (rows * (1.0 + 0.5 * np.sin(np.arange(n, dtype=np.float32)))[:, None]).astype(np.float32)  # unequal norms: cosine != dot order
     data = oracle.from_rows(rows)
     vb = B.VerticalBatch.from_rows(rows)
     qs = _queries(nq, dim, 4242, uniform=True)
+    engine = innr.KNN_MFMA_BF16 if filt == "bf16" else innr.KNN_MFMA_I8  # int8: the scalar-quantised corpus as the filter
     for metric, fn, ofn in (("dot", B.batch_knn_dot_multi, oracle.batch_knn_dot), ("cos", B.batch_knn_cosine_multi, oracle.batch_knn_cosine)):
         st = innr.KnnStats()
-        idx, sc = fn(qs, vb, k, engine=innr.KNN_MFMA_BF16, stats=st)
-        assert st.engine == innr.KNN_MFMA_BF16
+        idx, sc = fn(qs, vb, k, engine=engine, stats=st)
+        assert st.engine == engine
         for j, q in enumerate(qs):
             oi, os_ = ofn(q, data, k)
             assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j, idx[j], oi, sc[j], os_)
@@ -43,8 +45,15 @@ def test_bf16_cosine_zero_norms_and_auto(B, innr):
     vb = _check_knn(B, innr, "cos", rows, data, qs, 10, innr.KNN_MFMA_BF16)
     st = innr.KnnStats()
     B.batch_knn_cosine_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
-    assert st.engine == innr.KNN_MFMA_BF16  # the copy exists (and there is room for another): AUTO takes the fast filter
+    assert st.engine == innr.KNN_MFMA_I8  # there is room for the int8 filter copy: AUTO takes the fastest filter that applies
     _check_knn(B, innr, "cos", vb, data, qs, 10, innr.KNN_AUTO)
+    import os
+    os.environ["INNR_NO_AUTO_I8"] = "1"
+    try:
+        B.batch_knn_cosine_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
+        assert st.engine == innr.KNN_MFMA_BF16  # ... the bf16 one when the int8 one is ruled out (its copy exists already)
+    finally:
+        del os.environ["INNR_NO_AUTO_I8"]
     _check_knn(B, innr, "dot", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
     assert st.engine == innr.KNN_MFMA  # squared L2 stays on the f32 engine
@@ -89,3 +98,38 @@ def test_bf16_filter_on_a_prefix_view(B, innr):
     v = vb.prefix(64)
     _check_knn(B, innr, "dot", v, np.ascontiguousarray(data[:64]), np.ascontiguousarray(_queries(30, 128, 99, uniform=True)[:, :64]), 10,
                innr.KNN_MFMA_BF16)
+
+
+def test_int8_filter_of_f32_corpus_special_cases(B, innr):
+    """INNR_KNN_MFMA_I8 on an f32 batch: a corpus with outliers (the global range is wide, the bound large: proofs fail,
+    answers must not), a constant corpus (nothing to quantise against: the f32 engine serves it), non-finite values, squared L2
+    and k > 48 (served by the f32 engine), near-tie data, zero-norm rows / queries under cosine."""
+    rows, data = _corpus(70_000, 64, 13, uniform=True)
+    qs = _queries(40, 64, 3, uniform=True)
+    out = rows.copy()
+    out[5, 3] = 1e4
+    out[9, 0] = -3e3
+    _check_knn(B, innr, "dot", out, oracle.from_rows(out), qs, 10, innr.KNN_MFMA_I8)
+    _check_knn(B, innr, "cos", out, oracle.from_rows(out), qs, 10, innr.KNN_MFMA_I8)
+    const = np.full((70_000, 16), 0.5, np.float32)
+    st = innr.KnnStats()
+    vb = B.VerticalBatch.from_rows(const)
+    B.batch_knn_dot_multi(_queries(20, 16, 1, uniform=True), vb, 5, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA
+    _check_knn(B, innr, "dot", vb, oracle.from_rows(const), _queries(20, 16, 1, uniform=True), 5, innr.KNN_MFMA_I8)
+    bad = rows.copy()
+    bad[17, 3] = np.inf
+    _check_knn(B, innr, "dot", bad, oracle.from_rows(bad), qs, 5, innr.KNN_MFMA_I8)
+    vb = B.VerticalBatch.from_rows(rows)
+    B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA
+    B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA
+    _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_MFMA_I8)
+    z = rows.copy()
+    z[5] = 0.0
+    qz = qs.copy()
+    qz[3] = 0.0
+    _check_knn(B, innr, "cos", z, oracle.from_rows(z), qz, 10, innr.KNN_MFMA_I8)
+    lrows, ldata = _corpus(70_000, 128, 0)  # the reference example's LCG data: proofs fail, results must not
+    _check_knn(B, innr, "dot", lrows, ldata, _queries(24, 128), 10, innr.KNN_MFMA_I8)

@@ -347,6 +347,10 @@ def test_config5_cosine_4096_queries_two_logical_shards(B, innr):
         torch.cuda.synchronize()
         assert st2.engine == innr.KNN_MFMA_BF16 and torch.equal(bi, idx) and torch.equal(bs.view(torch.int32), sc.view(torch.int32))
         print(f"C5 shard {r} on the bf16 filter: gemm {st2.gemm_ms:.1f} ms, total {st2.total_ms:.1f} ms, fallback {st2.queries_fallback}")
+        ii, i_s = _gpu_local_search(vb, innr.METRIC_COSINE, innr.KNN_MFMA_I8)(q_dev, k, st2)  # the int8 filter (scalar-quantised copy)
+        torch.cuda.synchronize()
+        assert st2.engine == innr.KNN_MFMA_I8 and torch.equal(ii, idx) and torch.equal(i_s.view(torch.int32), sc.view(torch.int32))
+        print(f"C5 shard {r} on the int8 filter: gemm {st2.gemm_ms:.1f} ms, total {st2.total_ms:.1f} ms, fallback {st2.queries_fallback}")
         vb.close()
     out_i, out_s = _gpu_merge(ctx, innr.METRIC_COSINE)(all_i, all_s, k)
     torch.cuda.synchronize()

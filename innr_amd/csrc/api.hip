@@ -179,7 +179,8 @@ struct innr_batch {
     // bf16 filter engine (kernels_gemm_bf16.h): K-packed bf16 copy of the corpus, built on first use, always owned
     char* Ab = nullptr;
     char* Abn = nullptr;  // the same with every row scaled by 1/||v||: the cosine filter (built on the first cosine call)
-    uint32_t ab_nk = 0;
+    char* Abl = nullptr;  // the squared-L2 filter's copy: six more K columns per row (|v|^2 in three limbs, three ones)
+    uint32_t ab_nk = 0, abl_nk = 0;
     // int8 filter engine (kernels_gemm_i8.h): K-packed signed copy of the u8 codes, built on first use, always owned
     char* Ai8 = nullptr;
     uint32_t ai8_nk = 0;
@@ -672,15 +673,18 @@ static innr_status redo_batch(innr_batch* b, int metric, const float* dQ, const 
     return INNR_OK;
 }
 
-static uint32_t bf16_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b->D : 1, 64) / 32); }  // K-steps of 32, even
+enum { kBfDot = 0, kBfCos = 1, kBfL2 = 2 };  // which bf16 copy of the corpus a call filters on
+static uint32_t bf16_nk(const innr_batch* b, int variant = kBfDot) {  // K-steps of 32, even
+    return (uint32_t)(round_up((b->D ? b->D : 1) + (variant == kBfL2 ? kBfL2Extra : 0), 64) / 32);
+}
 
-static size_t bf16_copy_bytes(const innr_batch* b) { return (b->ldN / 128) * (size_t)bf16_nk(b) * 512 * 16; }
+static size_t bf16_copy_bytes(const innr_batch* b, int variant = kBfDot) { return (b->ldN / 128) * (size_t)bf16_nk(b, variant) * 512 * 16; }
 
 // normalised == true: the cosine copy (rows scaled by 1/||v||; needs b->invn)
-static innr_status ensure_bf16_corpus(innr_batch* b, bool normalised) {
-    char*& copy = normalised ? b->Abn : b->Ab;
+static innr_status ensure_bf16_corpus(innr_batch* b, int variant) {
+    char*& copy = variant == kBfCos ? b->Abn : (variant == kBfL2 ? b->Abl : b->Ab);
     if (copy) return INNR_OK;
-    const uint32_t nk = bf16_nk(b);
+    const uint32_t nk = bf16_nk(b, variant);
     const size_t units = (b->ldN / 128) * (size_t)nk * 512;  // 16-byte units
     hipError_t e = hipMalloc((void**)&copy, units * 16);
     if (e != hipSuccess) {
@@ -689,13 +693,14 @@ static innr_status ensure_bf16_corpus(innr_batch* b, bool normalised) {
         return INNR_E_OOM;
     }
     pack_corpus_bf16_kernel<<<(unsigned)((units + 255) / 256), 256, 0, b->ctx->stream>>>(
-        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk, units, reinterpret_cast<uint4*>(copy), normalised ? b->invn : nullptr);
+        b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk, units, reinterpret_cast<uint4*>(copy), variant == kBfCos ? b->invn : nullptr,
+        variant == kBfL2 ? b->sqn : nullptr);
     INNR_HIP_CHECK(hipGetLastError());
-    b->ab_nk = nk;
+    (variant == kBfL2 ? b->abl_nk : b->ab_nk) = nk;
     return INNR_OK;
 }
 
-static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed, bool normalised) {
+static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed, int variant) {
     innr_ctx* c = b->ctx;
     const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
     const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
@@ -706,7 +711,8 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nre
     INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
 #define INNR_BF16_LAUNCH(RR)                                                                                              \
     gemm_bf16_filter_kernel<RR, 0><<<p.nblocks, 64 * kBfWaves, 0, c->stream>>>(                                             \
-        normalised ? b->Abn : b->Ab, c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps, \
+        variant == kBfCos ? b->Abn : (variant == kBfL2 ? b->Abl : b->Ab), c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, \
+        variant == kBfL2 ? b->abl_nk : b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps,                                                  \
         c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, nullptr, 0)
     switch (p.cap) {
         case 384: INNR_BF16_LAUNCH(6); break;
@@ -725,11 +731,13 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     INNR_TRY(ensure_norms(b));  // exact norms: cosine epilogue + max norm for the dot / L2 error bounds
-    // bf16 filter: dot and cosine kinds (cosine = the plain dot of NORMALISED bf16 copies of corpus and queries: no norm is
-    // loaded in the kernel), candidate lists of 4k + 64 (its bound E is ~2^-7 |q||v|, so the k-th exact score must clear the
-    // KP-th approximate one by a visible margin), a corpus whose scores are far from the denormal range
-    const bool use_bf16 = bf16 && !l2 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
-                          (b->max_norm - b->max_norm == 0.0f);
+    // bf16 filter: every kind as the plain dot of bf16 copies (cosine: corpus and queries NORMALISED before the rounding;
+    // squared L2: six more K columns carry |v|^2 and the query's constant, pack_corpus_bf16_kernel) -- no norm is loaded in
+    // the kernel; candidate lists of 4k + 64 (its bound E is ~2^-7 |q||v|, so the k-th exact score must clear the KP-th
+    // approximate one by a visible margin), a corpus whose scores are far from the denormal range (L2: and from overflow)
+    const bool use_bf16 = bf16 && pick_kp(4 * kout + 64, 0) <= 256 && b->max_norm >= 1e-12f &&
+                          (b->max_norm - b->max_norm == 0.0f) && (!l2 || b->max_norm <= 1e15f);
+    const int bfv = cos ? kBfCos : (l2 ? kBfL2 : kBfDot);
     GemmPlan p = plan_gemm(b, Q, kout, use_bf16 ? 8 : 0, !cos && !l2);
     if (kp_force && !use_bf16 && kp_force >= p.KP && kp_force <= 256) {  // second attempt of redo_batch: longer lists
         p.KP = kp_force;
@@ -742,14 +750,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     if (cos) INNR_TRY(ensure_invnorms(b));
     if (l2) INNR_TRY(ensure_sqnorms(b));
     INNR_TRY(prep_queries(b, p, dQ, Q, cos));  // K-major queries, exact query norms (c->q_norm), cosine: 1/||q|| at c->misc
-    if (use_bf16) {
-        INNR_TRY(ensure_bf16_corpus(b, cos));
-        INNR_TRY(c->q_bf16.ensure((size_t)b->ab_nk * 4 * p.Qpad * 16));
-        pack_queries_bf16_kernel<<<(unsigned)(((size_t)b->ab_nk * 4 * p.Qpad + 255) / 256), 256, 0, c->stream>>>(
-            dQ, (uint32_t)Q, (uint32_t)b->D, b->ab_nk, (uint32_t)p.Qpad, reinterpret_cast<uint4*>(c->q_bf16.p),
-            cos ? c->misc.as<float>() : nullptr);
-        INNR_HIP_CHECK(hipGetLastError());
-    }
+    if (use_bf16) INNR_TRY(ensure_bf16_corpus(b, bfv));
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
@@ -765,6 +766,14 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
                                                                                        b->max_norm, invq, Cj);
         INNR_HIP_CHECK(hipGetLastError());
     }
+    if (use_bf16) {  // (after the L2 constants: the squared-L2 packing carries c_j = C_j - |q_j|^2 in three K columns)
+        const uint32_t nk = bf16_nk(b, bfv);
+        INNR_TRY(c->q_bf16.ensure((size_t)nk * 4 * p.Qpad * 16));
+        pack_queries_bf16_kernel<<<(unsigned)(((size_t)nk * 4 * p.Qpad + 255) / 256), 256, 0, c->stream>>>(
+            dQ, (uint32_t)Q, (uint32_t)b->D, nk, (uint32_t)p.Qpad, reinterpret_cast<uint4*>(c->q_bf16.p),
+            cos ? c->misc.as<float>() : nullptr, l2 ? invq : nullptr);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
 
 
     // dot / cosine: |approx - exact| <= (2D+8) u (1+eps) * sum|q_d v_d|: u = 2^-24, Cauchy-Schwarz for the sum.
@@ -776,7 +785,12 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     // bf16 filter: both operands rounded to 8 significant bits (|delta| <= 2^-8 each): |q'v' - qv| <= (2^-7 + 2^-16) |qv|,
     // plus the f32 accumulation of the rounded products
     // (cosine: both sides normalised before the rounding, |q^||v^| <= (1 + D u)^2 -- inside the 1.05)
-    const float bf16_scale = 1.05f * (0.0078125f * 1.004f + (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f * 1.02f) * (cos ? 1.0f : b->max_norm);
+    // squared L2 on the bf16 filter, as a multiple of C = (|q| + max|v|)^2: the doubled bf16 dot is off by <= 2 (2^-7 + 2^-16) |q||v|
+    // <= (2^-7 + 2^-16) C / 2; the f32 accumulation of D + 6 products whose absolute values sum to <= 2 C, the limbs' residuals,
+    // the cached norms and c_j, and the reference's own direct-difference sum (within (D+2) u of the true distance) stay
+    // inside (8D + 96) u C
+    const float bf16_scale = l2 ? 1.05f * (0.00390625f * 1.004f + (8.0f * (float)b->D + 96.0f) * 5.9604645e-08f)
+                                : 1.05f * (0.0078125f * 1.004f + (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f * 1.02f) * (cos ? 1.0f : b->max_norm);
     const float err_scale = use_bf16 ? bf16_scale
                                      : (l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm));
 
@@ -802,7 +816,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     }
 
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed, cos));
+    if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed, bfv));
     else if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
     else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, Q, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
     // (A first pass of the same kernel over 1/16 of the corpus, only to harvest tighter bounds for the full pass, was
@@ -1082,6 +1096,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
     if (b->Ab) (void)hipFree(b->Ab);
     if (b->Abn) (void)hipFree(b->Abn);
+    if (b->Abl) (void)hipFree(b->Abl);
     if (b->Ai8) (void)hipFree(b->Ai8);
     if (b->Ai8n) (void)hipFree(b->Ai8n);
     delete b;
@@ -1481,20 +1496,22 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
         // a batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
         // everything else with room to spare (copies are kept for the batch's lifetime): the int8 one first (N*D bytes, the
         // faster kernel), else the bf16 one (N*D*2 bytes).
-        if (engine == INNR_KNN_MFMA && Q >= 128 && metric != INNR_METRIC_L2SQ && pick_kp(4 * kout + 64, 0) <= 256 &&
-            !getenv("INNR_NO_AUTO_BF16")) {
+        if (engine == INNR_KNN_MFMA && Q >= 128 && pick_kp(4 * kout + 64, 0) <= 256 && !getenv("INNR_NO_AUTO_BF16")) {
             const bool cosm = metric == INNR_METRIC_COSINE;
+            const int bfv = cosm ? kBfCos : (metric == INNR_METRIC_L2SQ ? kBfL2 : kBfDot);
             size_t free_b = 0, total_b = 0;
             const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
             const size_t slack = (size_t)8 << 30;
             if (f32_i8_eligible(b, metric, Q, kout) && !getenv("INNR_NO_AUTO_I8") && !(cosm ? b->i8n_weak : b->i8_weak) &&
                 ((cosm ? b->Ai8n : b->Ai8) != nullptr || (have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
                 engine = INNR_KNN_MFMA_I8;
-            else if ((cosm ? b->Abn : b->Ab) != nullptr || (have_mem && free_b > 2 * bf16_copy_bytes(b) + slack))
+            else if ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
+                     (have_mem && free_b > 2 * bf16_copy_bytes(b, bfv) + slack))
                 engine = INNR_KNN_MFMA_BF16;
         }
     }
-    if (engine == INNR_KNN_MFMA_I8 && !f32_i8_eligible(b, metric, Q, kout)) engine = INNR_KNN_MFMA;  // squared L2, k > 48, a view ...
+    if (engine == INNR_KNN_MFMA_I8 && !f32_i8_eligible(b, metric, Q, kout))  // squared L2 (the bf16 filter has it), k > 48, a view ...
+        engine = metric == INNR_METRIC_L2SQ ? INNR_KNN_MFMA_BF16 : INNR_KNN_MFMA;
     if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16 || engine == INNR_KNN_MFMA_I8) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));

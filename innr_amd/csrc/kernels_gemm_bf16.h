@@ -35,12 +35,28 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
     return (uint16_t)(b >> 16);
 }
 
+// limb l of x as a sum of bf16 values: x = limb0 + limb1 + limb2 up to 2^-24 |x| (each difference below is exact in f32)
+__device__ __forceinline__ uint16_t bf16_limb(float x, int l) {
+    uint16_t h = f32_to_bf16_rne(x);
+    for (int t = 0; t < l; ++t) {
+        x -= __uint_as_float((uint32_t)h << 16);
+        h = f32_to_bf16_rne(x);
+    }
+    return h;
+}
+constexpr uint32_t kBfL2Extra = 6;  // the squared-L2 copy's additional K columns
+
 // one thread per 16-byte output unit (8 dimensions of one corpus row)
 // rowscale (nullable): 1/||v|| per row (0 for zero-norm rows) -- the COSINE copy holds the normalised rows, so that the plain
 // dot of the filter kernel IS the approximate cosine (with the queries normalised the same way) and no norm is loaded per tile
+// sqn (nullable): |v|^2 per row -- the SQUARED-L2 copy carries six more K columns per row, [three bf16 limbs of |v|^2, 1, 1, 1],
+// against [-1, -1, -1, three limbs of c_j] and DOUBLED queries on the other side: the plain dot of the filter kernel is then
+// 2 q.v - |v|^2 + c_j = C_j - |q - v|^2 up to rounding (c_j = C_j - |q_j|^2 >= 0 as for kGemmL2, kernels_gemm.h), no norm is
+// loaded per tile and the score is non-negative where it matters (the raw-bit fast reject of the epilogue)
 __global__ __launch_bounds__(256) void pack_corpus_bf16_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
                                                                 uint32_t nk, size_t units, uint4* __restrict__ Ab,
-                                                                const float* __restrict__ rowscale = nullptr) {
+                                                                const float* __restrict__ rowscale = nullptr,
+                                                                const float* __restrict__ sqn = nullptr) {
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= units) return;
     const uint32_t i = (uint32_t)(u & 31), rt = (uint32_t)((u >> 5) & 3), kg = (uint32_t)((u >> 7) & 3);
@@ -53,6 +69,8 @@ __global__ __launch_bounds__(256) void pack_corpus_bf16_kernel(const float* __re
     for (int e = 0; e < 8; ++e) {
         const uint32_t d = ks * 32 + kg * 8 + e;
         h[e] = (row < N && d < D) ? f32_to_bf16_rne(V[(size_t)d * ldN + row] * rs) : (uint16_t)0;
+        if (sqn && row < N && d >= D && d < D + kBfL2Extra)
+            h[e] = (d - D < 3) ? bf16_limb(sqn[row], (int)(d - D)) : (uint16_t)0x3F80u;  // limbs of |v|^2, then 1.0 three times
     }
     uint4 o;
     o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);
@@ -61,20 +79,24 @@ __global__ __launch_bounds__(256) void pack_corpus_bf16_kernel(const float* __re
 }
 
 // queries row-major [Q][D] -> Bb; one thread per 16-byte unit
+// l2c (nullable; [Qpad] c_j = C_j - |q_j|^2): the squared-L2 packing, see pack_corpus_bf16_kernel
 __global__ __launch_bounds__(256) void pack_queries_bf16_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, uint32_t nk,
                                                                  uint32_t Qpad, uint4* __restrict__ Bb,
-                                                                 const float* __restrict__ qscale = nullptr) {
+                                                                 const float* __restrict__ qscale = nullptr,
+                                                                 const float* __restrict__ l2c = nullptr) {
     const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= (size_t)nk * 4 * Qpad) return;
     const uint32_t pos = (uint32_t)(u % Qpad);
     const uint32_t kk = (uint32_t)(u / Qpad);  // ks * 4 + kg
     const uint32_t q = (pos & ~63u) + 2 * (pos & 31) + ((pos >> 5) & 1);
-    const float qs = (qscale && q < Q) ? qscale[q] : 1.0f;  // cosine: 1/||q|| (0 below the reference's epsilon)
+    const float qs = l2c ? 2.0f : ((qscale && q < Q) ? qscale[q] : 1.0f);  // cosine: 1/||q|| (0 below the reference's epsilon)
     uint16_t h[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const uint32_t d = kk * 8 + e;
         h[e] = (q < Q && d < D) ? f32_to_bf16_rne(Qm[(size_t)q * D + d] * qs) : (uint16_t)0;
+        if (l2c && q < Q && d >= D && d < D + kBfL2Extra)
+            h[e] = (d - D < 3) ? (uint16_t)0xBF80u : bf16_limb(l2c[q], (int)(d - D - 3));  // -1.0 three times, then limbs of c_j
     }
     uint4 o;
     o.x = h[0] | ((uint32_t)h[1] << 16); o.y = h[2] | ((uint32_t)h[3] << 16);

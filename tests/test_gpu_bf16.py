@@ -22,10 +22,12 @@ def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k, filt):
     vb = B.VerticalBatch.from_rows(rows)
     qs = _queries(nq, dim, 4242, uniform=True)
     engine = innr.KNN_MFMA_BF16 if filt == "bf16" else innr.KNN_MFMA_I8  # int8: the scalar-quantised corpus as the filter
-    for metric, fn, ofn in (("dot", B.batch_knn_dot_multi, oracle.batch_knn_dot), ("cos", B.batch_knn_cosine_multi, oracle.batch_knn_cosine)):
+    for metric, fn, ofn in (("dot", B.batch_knn_dot_multi, oracle.batch_knn_dot), ("cos", B.batch_knn_cosine_multi, oracle.batch_knn_cosine),
+                            ("l2", B.batch_knn_multi, oracle.batch_knn)):
         st = innr.KnnStats()
         idx, sc = fn(qs, vb, k, engine=engine, stats=st)
-        assert st.engine == engine
+        # squared L2 has no int8 filter: the bf16 one (|v|^2 and the query's constant in six more K columns) serves it
+        assert st.engine == (innr.KNN_MFMA_BF16 if metric == "l2" else engine)
         for j, q in enumerate(qs):
             oi, os_ = ofn(q, data, k)
             assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j, idx[j], oi, sc[j], os_)
@@ -56,7 +58,8 @@ def test_bf16_cosine_zero_norms_and_auto(B, innr):
         del os.environ["INNR_NO_AUTO_I8"]
     _check_knn(B, innr, "dot", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
-    assert st.engine == innr.KNN_MFMA  # squared L2 stays on the f32 engine
+    assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter (there is no int8 one for it)
+    _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_AUTO, stats=st)
     assert st.engine == innr.KNN_MFMA  # k > 48: the candidate lists of the bf16 filter would not fit
 
@@ -67,15 +70,28 @@ def test_bf16_filter_near_ties_are_redone_exactly(B, innr):
     _check_knn(B, innr, "dot", rows, data, _queries(40, 128), 10, innr.KNN_MFMA_BF16)
 
 
-def test_bf16_engine_serves_other_kinds_on_the_f32_engine(B, innr):
+def test_bf16_engine_l2_and_what_the_f32_engine_still_serves(B, innr):
     rows, data = _corpus(70_000, 64, 5, uniform=True)
     vb = B.VerticalBatch.from_rows(rows)
     qs = _queries(20, 64, 9, uniform=True)
-    for metric, fn in (("l2", B.batch_knn_multi),):
-        st = innr.KnnStats()
-        fn(qs, vb, 10, engine=innr.KNN_MFMA_BF16, stats=st)
-        assert st.engine == innr.KNN_MFMA
-        _check_knn(B, innr, metric, vb, data, qs, 10, innr.KNN_MFMA_BF16)
+    st = innr.KnnStats()
+    for engine in (innr.KNN_MFMA_BF16, innr.KNN_MFMA_I8):
+        B.batch_knn_multi(qs, vb, 10, engine=engine, stats=st)
+        assert st.engine == innr.KNN_MFMA_BF16 and st.queries_fallback <= 2
+        _check_knn(B, innr, "l2", vb, data, qs, 10, engine)
+    # D + 6 columns no longer fit the last K-step pair (D = 64 -> 128 columns), a query far outside the corpus, a zero query,
+    # a zero row, a corpus far from the origin (|v|^2 dwarfs the differences: proofs fail, answers must not)
+    qs2 = qs.copy()
+    qs2[0] *= 1e3
+    qs2[1] = 0.0
+    rows2 = rows.copy()
+    rows2[11] = 0.0
+    _check_knn(B, innr, "l2", rows2, oracle.from_rows(rows2), qs2, 7, innr.KNN_MFMA_BF16)
+    far = (rows + np.float32(300.0)).astype(np.float32)
+    _check_knn(B, innr, "l2", far, oracle.from_rows(far), (qs + np.float32(300.0)).astype(np.float32), 5, innr.KNN_MFMA_BF16)
+    huge = (rows * np.float32(1e17)).astype(np.float32)  # |v|^2 would overflow: the f32 engine's direct differences serve it
+    B.batch_knn_multi(qs, B.VerticalBatch.from_rows(huge), 5, engine=innr.KNN_MFMA_BF16, stats=st)
+    assert st.engine == innr.KNN_MFMA
     st = innr.KnnStats()
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_BF16, stats=st)  # k > 48: candidate lists would not fit
     assert st.engine == innr.KNN_MFMA
@@ -88,22 +104,25 @@ def test_bf16_filter_tiny_and_special_values(B, innr):
     tiny = (rows * np.float32(1e-20)).astype(np.float32)
     qs = _queries(6, 64, 1, uniform=True)
     _check_knn(B, innr, "dot", tiny, oracle.from_rows(tiny), (qs * np.float32(1e-18)).astype(np.float32), 10, innr.KNN_MFMA_BF16)
+    _check_knn(B, innr, "l2", tiny, oracle.from_rows(tiny), (qs * np.float32(1e-18)).astype(np.float32), 10, innr.KNN_MFMA_BF16)
     rows[17, 3] = np.inf  # a non-finite norm: nothing can be proven
     _check_knn(B, innr, "dot", rows, oracle.from_rows(rows), qs, 5, innr.KNN_MFMA_BF16)
+    _check_knn(B, innr, "l2", rows, oracle.from_rows(rows), qs, 5, innr.KNN_MFMA_BF16)
 
 
 def test_bf16_filter_on_a_prefix_view(B, innr):
     rows, data = _corpus(70_000, 128, 11, uniform=True)
     vb = B.VerticalBatch.from_rows(rows)
     v = vb.prefix(64)
-    _check_knn(B, innr, "dot", v, np.ascontiguousarray(data[:64]), np.ascontiguousarray(_queries(30, 128, 99, uniform=True)[:, :64]), 10,
-               innr.KNN_MFMA_BF16)
+    for metric in ("dot", "l2"):
+        _check_knn(B, innr, metric, v, np.ascontiguousarray(data[:64]), np.ascontiguousarray(_queries(30, 128, 99, uniform=True)[:, :64]), 10,
+                   innr.KNN_MFMA_BF16)
 
 
 def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     """INNR_KNN_MFMA_I8 on an f32 batch: a corpus with outliers (the global range is wide, the bound large: proofs fail,
     answers must not), a constant corpus (nothing to quantise against: the f32 engine serves it), non-finite values, squared L2
-    and k > 48 (served by the f32 engine), near-tie data, zero-norm rows / queries under cosine."""
+    and k > 48 (served by the bf16 filter resp. the f32 engine), near-tie data, zero-norm rows / queries under cosine."""
     rows, data = _corpus(70_000, 64, 13, uniform=True)
     qs = _queries(40, 64, 3, uniform=True)
     out = rows.copy()
@@ -122,7 +141,7 @@ def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     _check_knn(B, innr, "dot", bad, oracle.from_rows(bad), qs, 5, innr.KNN_MFMA_I8)
     vb = B.VerticalBatch.from_rows(rows)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_MFMA_I8, stats=st)
-    assert st.engine == innr.KNN_MFMA
+    assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_I8, stats=st)
     assert st.engine == innr.KNN_MFMA
     _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_MFMA_I8)

@@ -1923,13 +1923,15 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
     // a code corpus that stays in the Infinity Cache: all 4-query groups in one launch (see knn_exact_range)
     size_t max_groups = 1;
     if (cols * b->D <= (size_t)128 << 20)
-        max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * 4 * cap * sizeof(uint64_t)));
+        max_groups = std::max<size_t>(1, ((size_t)256 << 20) / (nslots * 8 * cap * sizeof(uint64_t)));
     max_groups = std::min<size_t>(max_groups, 65535);
     size_t done = 0;
     while (done < nq) {
         const size_t rem = nq - done;
-        const uint32_t qb = rem >= 2 ? 4 : 1;  // 2-3 queries: one 4-query pass padded with zero rows (cf. knn_exact_range)
-        const uint32_t groups = (qb == 4 && rem >= 4) ? (uint32_t)std::min<size_t>(rem / 4, max_groups) : 1u;
+        // 2-3 queries: one 4-query pass padded with zero rows, 5-7: one 8-query pass (cf. knn_exact_range); the 8-query pass
+        // costs less than two of 4 (one corpus stream, one widening of each code)
+        const uint32_t qb = rem >= 5 ? 8 : (rem >= 2 ? 4 : 1);
+        const uint32_t groups = (qb > 1 && rem >= qb) ? (uint32_t)std::min<size_t>(rem / qb, max_groups) : 1u;
         const uint32_t nql = qb * groups;
         const uint32_t nreal = (uint32_t)std::min<size_t>(nql, rem);
         INNR_TRY(c->lists.ensure(nslots * nql * cap * sizeof(uint64_t)));
@@ -1948,7 +1950,8 @@ static innr_status knn_u8_exact_range(innr_batch* b, const float* dQ, size_t ldq
             q = c->q_pad.as<float>();
             qs = qs_pad;
         }
-        if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n, nreal < nql ? nreal : 0xFFFFFFFFu));
+        if (qb == 8) INNR_TRY(launch_scan_u8<8>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n, nreal < nql ? nreal : 0xFFFFFFFFu));
+        else if (qb == 4) INNR_TRY(launch_scan_u8<4>(b, q, ldq, qs, nblocks, KP, cap, cps, groups, limit_n, nreal < nql ? nreal : 0xFFFFFFFFu));
         else INNR_TRY(launch_scan_u8<1>(b, q, ldq, qs, nblocks, KP, cap, cps, 1, limit_n));
         INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), (uint32_t)nslots, nql, cap, KP, nql));
         const uint32_t total = nreal * (uint32_t)kout;

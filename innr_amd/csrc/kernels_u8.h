@@ -17,6 +17,13 @@
 
 namespace innr {
 
+#ifndef INNR_U8_UNROLL
+#define INNR_U8_UNROLL 8
+#endif
+constexpr int kU8Unroll = INNR_U8_UNROLL;
+#ifndef INNR_U8_DIMBARRIER
+#define INNR_U8_DIMBARRIER 1
+#endif
 constexpr int kU8Chunk = 64 * 16;  // vectors per wave step (64 lanes x 16 codes)
 
 // quantize_u8 (scalar.rs:212-225): clamp(round((v - offset) * (255/alpha)), 0, 255); round = half away from zero
@@ -183,13 +190,20 @@ __device__ __forceinline__ void scan_u8_accumulate(const uint8_t* __restrict__ C
         for (int c = 0; c < 16; ++c) acc[j][c] = -0.0f;  // <f32 as Sum>::sum starts at -0.0 (scalar.rs:357)
     const uint4* p = reinterpret_cast<const uint4*>(C + col);
     const size_t stride = ldN / 16;
+    // kU8Unroll dimensions per iteration, ALL their loads issued at its top (the sched_barrier keeps the scheduler from sinking
+    // each load next to its use, which serialises load -> wait -> multiply; seen with an 8-fold unroll) and awaited one by
+    // one (the compiler counts them down within an iteration). Loads carried ACROSS the back-edge it awaits with vmcnt(0), and
+    // hand-placed asm loads + waits made the allocator copy registers whose data had not arrived -- both tried. What hides
+    // the first load's round trip is the other waves of the SIMD, so an iteration must be long: 8 dimensions.
+#if INNR_U8_UNROLL == 0  // (tools/u8_scan_probe.hip: round 1's loop, for comparison)
+    uint32_t d = 0;
 #pragma unroll 4
-    for (uint32_t d = 0; d < D; ++d) {
+    for (; d < D; ++d) {
         const uint4 v = p[(size_t)d * stride];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         float f[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) f[c] = (float)((w[c >> 2] >> (8 * (c & 3))) & 0xffu);  // u8 -> f32, exact
+        for (int c = 0; c < 16; ++c) f[c] = (float)((w[c >> 2] >> (8 * (c & 3))) & 0xffu);
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
             const float q = Qm[(size_t)j * ldq + d];
@@ -197,6 +211,46 @@ __device__ __forceinline__ void scan_u8_accumulate(const uint8_t* __restrict__ C
             for (int c = 0; c < 16; ++c) acc[j][c] = ex::mad2(acc[j][c], q, f[c]);
         }
     }
+#else
+    constexpr int U = QB <= 4 ? kU8Unroll : (kU8Unroll < 4 ? kU8Unroll : 4);
+    uint32_t d = 0;
+#pragma unroll 1
+    for (; d + U <= D; d += U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(size_t)(d + u) * stride];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float f[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) f[c] = (float)((w[c >> 2] >> (8 * (c & 3))) & 0xffu);  // u8 -> f32, exact
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                const float q = Qm[(size_t)j * ldq + d + u];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[j][c] = ex::mad2(acc[j][c], q, f[c]);
+            }
+#if INNR_U8_DIMBARRIER
+            __builtin_amdgcn_sched_barrier(0);  // one dimension's 16 widened codes live at a time, not the iteration's 128
+#endif
+        }
+    }
+    for (; d < D; ++d) {
+        const uint4 v = p[(size_t)d * stride];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float f[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) f[c] = (float)((w[c >> 2] >> (8 * (c & 3))) & 0xffu);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const float q = Qm[(size_t)j * ldq + d];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[j][c] = ex::mad2(acc[j][c], q, f[c]);
+        }
+    }
+#endif
 }
 
 // every document's score: out[j*ldo + i] (the map inside batch_knn_u8, scalar.rs:384-388)

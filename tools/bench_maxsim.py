@@ -3,14 +3,13 @@ top-100, 1 GPU. Prints one JSON line (roofline: HBM, 4*docs*T*dim bytes per quer
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import oracle
 from innr_amd import KNN_EXACT, KNN_MFMA, KnnStats
 from innr_amd import maxsim as M
 
 ndocs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 T, dim, Tq, k = 64, 128, 32, 100
 dc = M.DocumentCorpus.generate(ndocs, T, dim, seed=0)
-rng = oracle.generate_uniform(Tq, dim, 123)
+rng = np.random.default_rng(123).uniform(-1.0, 1.0, size=(Tq, dim)).astype(np.float32)
 q = rng / np.sqrt((rng.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
 out = {}
 for name, cos in (("maxsim", False), ("maxsim_cosine", True)):
@@ -33,7 +32,7 @@ for name, cos in (("maxsim", False), ("maxsim_cosine", True)):
 # several queries per call: four share each corpus pass on the MFMA engine
 qs8 = []
 for j in range(8):
-    r = oracle.generate_uniform(Tq, dim, 500 + j)
+    r = np.random.default_rng(500 + j).uniform(-1.0, 1.0, size=(Tq, dim)).astype(np.float32)
     qs8.append((r / np.sqrt((r.astype(np.float64) ** 2).sum(axis=1, keepdims=True))).astype(np.float32))
 best = None
 for it in range(3):

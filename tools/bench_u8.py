@@ -16,7 +16,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-import oracle
 from innr_amd import KNN_EXACT, KNN_MFMA, KNN_MFMA_I8, KnnStats
 from innr_amd import scalar as S
 
@@ -29,7 +28,7 @@ engine = KNN_MFMA_I8 if which == "i8" else KNN_MFMA
 dim, nq, k = 768, 1024, 100
 p = S.QuantizationParams.from_range(-1.0, 1.0)
 qc = S.QuantizedCorpus.generate(n, dim, p, seed=0)
-qs = oracle.generate_uniform(nq, dim, 0xBE7C)
+qs = np.random.default_rng(0xBE7C).uniform(-1.0, 1.0, size=(nq, dim)).astype(np.float32)
 best = None
 for it in range(4):
     st = KnnStats()

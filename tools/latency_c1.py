@@ -3,13 +3,12 @@ API on one GPU -- one query per call (the reference's signature) and the whole b
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import oracle
 from innr_amd import KNN_EXACT, KNN_MFMA, KnnStats
 from innr_amd import batch as B
 
 n, dim, nq, k = 10_000, 128, 100, 10
 vb = B.VerticalBatch.generate(n, dim, seed=0)
-qs = oracle.generate_uniform(nq, dim, 50_000)
+qs = np.random.default_rng(50_000).uniform(-1.0, 1.0, size=(nq, dim)).astype(np.float32)
 for _ in range(3):
     B.batch_knn_dot(qs[0], vb, k)
 t0 = time.perf_counter()

@@ -2,14 +2,13 @@
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import oracle
 from innr_amd import KNN_EXACT, KnnStats
 from innr_amd import scalar as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 dim, k = 768, 100
 p = S.QuantizationParams.from_range(-1.0, 1.0)
 qc = S.QuantizedCorpus.generate(n, dim, p, seed=0)
-qs = oracle.generate_uniform(16, dim, 0xBE7C)
+qs = np.random.default_rng(0xBE7C).uniform(-1.0, 1.0, size=(16, dim)).astype(np.float32)
 for nq in (1, 4, 8, 16):
     best = 1e9
     for _ in range(3):

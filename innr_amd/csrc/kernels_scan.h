@@ -17,8 +17,35 @@ namespace innr {
 constexpr int kScanThreads = 256;          // 4 waves
 constexpr int kScanChunk = 64 * 4;         // vectors per wave step (64 lanes x float4)
 
+// one dimension d of 4 vectors against QB queries
+template <int QB, bool L2>
+__device__ __forceinline__ void scan_dim(float (&acc)[QB][4], const float4& v, const float* __restrict__ Qm, size_t ldq, uint32_t d) {
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const float q = Qm[(size_t)j * ldq + d];  // wave-uniform -> scalar load
+        if (L2) {  // batch.rs:262-263: diff = q_d - v_d; dist += diff*diff
+            const float d0 = ex::sub_keepnan(q, v.x), d1 = ex::sub_keepnan(q, v.y), d2 = ex::sub_keepnan(q, v.z),
+                        d3 = ex::sub_keepnan(q, v.w);
+            acc[j][0] = ex::mad2(acc[j][0], d0, d0);
+            acc[j][1] = ex::mad2(acc[j][1], d1, d1);
+            acc[j][2] = ex::mad2(acc[j][2], d2, d2);
+            acc[j][3] = ex::mad2(acc[j][3], d3, d3);
+        } else {  // batch.rs:294: prod += q_d * v_d
+            acc[j][0] = ex::mad2(acc[j][0], q, v.x);
+            acc[j][1] = ex::mad2(acc[j][1], q, v.y);
+            acc[j][2] = ex::mad2(acc[j][2], q, v.z);
+            acc[j][3] = ex::mad2(acc[j][3], q, v.w);
+        }
+    }
+}
+
 // acc[j][c] for QB queries x 4 vectors starting at column `col` (col % 4 == 0, col + 3 < ldN).
 // ORD: walk the dimensions in the order given by `order[0..D)` (batch_knn_reordered, batch.rs:640-648).
+// Groups of kScanGroup dimensions, ALL their loads issued at the top of the iteration and awaited one by one: left to the
+// scheduler (a plain 8-fold unroll), the 4- and 8-query instantiations came out as load -> vmcnt(0) -> multiply, one
+// dimension after the other, each round trip covered only by the other waves of the SIMD (kernels_u8.h has the same shape
+// and the measurements behind it).
+constexpr int kScanGroup = 8;
 template <int QB, bool L2, bool ORD = false>
 __device__ __forceinline__ void scan_accumulate(const float* __restrict__ V, size_t ldN, uint32_t D, size_t col,
                                                 const float* __restrict__ Qm, size_t ldq, float (&acc)[QB][4],
@@ -27,27 +54,25 @@ __device__ __forceinline__ void scan_accumulate(const float* __restrict__ V, siz
     for (int j = 0; j < QB; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f;
     const float4* p = reinterpret_cast<const float4*>(V + col);
     const size_t stride = ldN / 4;
-#pragma unroll 8
-    for (uint32_t t = 0; t < D; ++t) {
+    constexpr int U = kScanGroup;
+    uint32_t t = 0;
+#pragma unroll 1
+    for (; t + U <= D; t += U) {
+        float4 v[U];
+        uint32_t dd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dd[u] = (ORD && order) ? order[t + u] : t + u;
+            v[u] = p[(size_t)dd[u] * stride];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) scan_dim<QB, L2>(acc, v[u], Qm, ldq, dd[u]);
+    }
+    for (; t < D; ++t) {
         const uint32_t d = (ORD && order) ? order[t] : t;
         const float4 v = p[(size_t)d * stride];
-#pragma unroll
-        for (int j = 0; j < QB; ++j) {
-            const float q = Qm[(size_t)j * ldq + d];  // wave-uniform -> scalar load
-            if (L2) {  // batch.rs:262-263: diff = q_d - v_d; dist += diff*diff
-                const float d0 = ex::sub_keepnan(q, v.x), d1 = ex::sub_keepnan(q, v.y), d2 = ex::sub_keepnan(q, v.z),
-                            d3 = ex::sub_keepnan(q, v.w);
-                acc[j][0] = ex::mad2(acc[j][0], d0, d0);
-                acc[j][1] = ex::mad2(acc[j][1], d1, d1);
-                acc[j][2] = ex::mad2(acc[j][2], d2, d2);
-                acc[j][3] = ex::mad2(acc[j][3], d3, d3);
-            } else {  // batch.rs:294: prod += q_d * v_d
-                acc[j][0] = ex::mad2(acc[j][0], q, v.x);
-                acc[j][1] = ex::mad2(acc[j][1], q, v.y);
-                acc[j][2] = ex::mad2(acc[j][2], q, v.z);
-                acc[j][3] = ex::mad2(acc[j][3], q, v.w);
-            }
-        }
+        scan_dim<QB, L2>(acc, v, Qm, ldq, d);
     }
 }
 

@@ -52,8 +52,10 @@ typedef int innr_status;
 #define INNR_KNN_MFMA_BF16 3 /* the same with the FILTER on the bf16 matrix pipe (16x the f32 MFMA rate) over a K-packed bf16
                               * copy of the corpus built on first use (+ N*D*2 bytes of HBM). Results are unchanged -- the
                               * candidates are re-scored in the reference's f32 order and the answer is proven against the
-                              * bf16 error bound, unproven queries are redone exactly. Dot metric with k <= 48; every other
-                              * call is served by INNR_KNN_MFMA (innr_knn_stats.engine tells). Not chosen by INNR_KNN_AUTO. */
+                              * bf16 error bound, unproven queries are redone exactly. Every metric with k <= 48 (cosine: a copy
+                              * of the normalised rows; squared L2: a copy with |v|^2 in six more K columns); other calls are
+                              * served by INNR_KNN_MFMA (innr_knn_stats.engine tells). INNR_KNN_AUTO picks a low-precision filter
+                              * (this one, or INNR_KNN_MFMA_I8 where it applies) for >= 128 queries when the copy exists or fits. */
 
 #define INNR_KNN_MFMA_I8 4 /* the filter on the INTEGER matrix pipe (v_mfma_i32_32x32x32_i8: twice the bf16 MFMA rate, 32x the f32 one).
                             * innr_batch_knn_u8[_dev]: over a K-packed signed copy of the codes built on first use (+ N*D bytes of
@@ -61,7 +63,7 @@ typedef int innr_status;
                             * limb bounded in the filter and computed exactly for the survivors (lists of 256: a 16-bit value, both
                             * limbs on the pipe). Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call.
                             * INNR_KNN_AUTO picks it for query batches on large code corpora.
-                            * innr_batch_knn[_dev] on an F32 batch (dot, cosine; k <= 48): the corpus scalar-quantised once with a
+                            * innr_batch_knn[_dev] on an F32 batch (dot, cosine; k <= 48; squared L2 goes to INNR_KNN_MFMA_BF16): the corpus scalar-quantised once with a
                             * single (offset, alpha) -- quantize_u8 with the corpus' own range, the first stage of the two-stage
                             * pipeline of scalar.rs:366-368 -- filtered on the integer pipe, re-scored on the f32 corpus and
                             * PROVEN against (alpha / 510) |q|_1 + the query's quantisation; unproven queries redone on the f32
@@ -78,7 +80,7 @@ typedef struct innr_batch innr_batch; /* device-resident VerticalBatch (PDX, dim
 
 /* what a kNN call did (optional out-parameter; all fields written) */
 typedef struct innr_knn_stats {
-    int engine;                 /* INNR_KNN_EXACT, INNR_KNN_MFMA or INNR_KNN_MFMA_BF16 actually used */
+    int engine;                 /* INNR_KNN_EXACT, INNR_KNN_MFMA, INNR_KNN_MFMA_BF16 or INNR_KNN_MFMA_I8 actually used */
     uint32_t queries_fallback;  /* MFMA engine: queries whose margin proof failed and were redone exactly */
     uint32_t candidates_kept;   /* k' = candidates per query kept before the exact re-score */
     float gemm_ms;              /* device time of the dominant kernel (HIP events on the ctx stream) */

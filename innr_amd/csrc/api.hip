@@ -832,7 +832,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
                                                                  c->q_norm.as<float>(), Cj, c->sel.as<uint64_t>(),  \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout,   \
                                                                  err_scale, b->index_base, d_out_idx, d_out_score,  \
-                                                                 fallback)
+                                                                 fallback, nullptr, !getenv("INNR_RESCORE_ALL"))
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
         if (rk == 1) INNR_RESCORE(1, 1); else if (rk == 2) INNR_RESCORE(1, 2); else INNR_RESCORE(1, 4);
@@ -2025,7 +2025,7 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
                                                               (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
-                                                              d_out_score, fallback)
+                                                              d_out_score, fallback, nullptr, !getenv("INNR_RESCORE_ALL"))
     if (p.KP <= 64) INNR_RESCORE_U8(1);
     else if (p.KP <= 128) INNR_RESCORE_U8(2);
     else INNR_RESCORE_U8(4);
@@ -2200,7 +2200,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
                                                               (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
-                                                              d_out_score, fallback, qc + 3 * p.Qpad)
+                                                              d_out_score, fallback, qc + 3 * p.Qpad, !getenv("INNR_RESCORE_ALL"))
     if (p.KP <= 64) INNR_RESCORE_U8(1);
     else if (p.KP <= 128) INNR_RESCORE_U8(2);
     else INNR_RESCORE_U8(4);
@@ -2372,7 +2372,8 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,           \
                                                                  c->q_norm.as<float>(), nullptr, c->sel.as<uint64_t>(), \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout, 0.0f, \
-                                                                 b->index_base, d_out_idx, d_out_score, fallback, eq)
+                                                                 b->index_base, d_out_idx, d_out_score, fallback, eq,   \
+                                                                 !getenv("INNR_RESCORE_ALL"))
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
         if (rk == 1) INNR_RESCORE_EQ(1, 1); else if (rk == 2) INNR_RESCORE_EQ(1, 2); else INNR_RESCORE_EQ(1, 4);

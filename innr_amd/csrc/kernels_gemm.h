@@ -452,6 +452,11 @@ __global__ void inv_qnorms_kernel(const float* __restrict__ x, size_t n, size_t 
 //   enough that exact(k-th best candidate) > T + E. Failing queries are flagged for the exact engine.
 // MET: 0 dot, 1 cosine, 2 squared L2 (direct differences, batch.rs:262-263; smaller is better; qaux[q] = C_q of the
 // GEMM epilogue, err_scale * C_q bounds |C_q - approx - exact distance|).
+// Progressive (early = true; the candidates are sorted best-first by approximate score): the wave re-scores them in
+// rounds -- the best 32, the next 32, then 64, then 128 -- and stops at the first round after which the proof holds with
+// T = the approximate score of the best candidate NOT yet re-scored (every such candidate, and every outsider, has approx <= T).
+// The column gathers of the re-score are sector traffic (4 useful bytes per line fetched): at C2 the low-precision filters
+// kept 128 candidates per query and spent 2.0 ms re-scoring them, although the answer was usually proven by the first 32.
 template <int MET, int RK>
 __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V, size_t ldN, uint32_t D,
                                                      const float* __restrict__ Qm, const float* __restrict__ norms,
@@ -460,7 +465,8 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
                                                      const uint32_t* __restrict__ sel_cnt, uint32_t KP, uint32_t kout,
                                                      float err_scale, uint64_t index_base,
                                                      uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                     uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr) {
+                                                     uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr,
+                                                     bool early = false) {
     constexpr bool COS = MET == 1, L2 = MET == 2;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -469,73 +475,87 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
     const float qn = L2 ? 0.0f : qnorm[q];
     uint64_t e[RK];
 #pragma unroll
-    for (int r = 0; r < RK; ++r) {
-        const uint32_t c = r * 64 + lane;
-        e[r] = 0;
-        if (c < cnt) {
-            const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
-            const float* col = V + i;
-            float acc = 0.0f;
-            if (L2) {
-#pragma unroll 8
-                for (uint32_t d = 0; d < D; ++d) {
-                    const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
-                    acc = ex::mad2(acc, diff, diff);
-                }
-            } else {
-#pragma unroll 8
-                for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
-            }
-            if (COS) {
-                const float vn = norms[i];
-                acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
-            }
-            e[r] = cand_make(score_pref<L2>(acc), i);
-        }
-    }
-    uint32_t rank[RK];
-#pragma unroll
-    for (int r = 0; r < RK; ++r) rank[r] = 0;
-#pragma unroll
-    for (int r2 = 0; r2 < RK; ++r2) {
-        if ((uint32_t)(r2 * 64) < cnt) {
-            const int lim = (cnt - r2 * 64) < 64u ? (int)(cnt - r2 * 64) : 64;
-            for (int l = 0; l < lim; ++l) {
-                const uint64_t bcast = readlane_u64(e[r2], l);
-#pragma unroll
-                for (int r = 0; r < RK; ++r) rank[r] += (bcast > e[r]) ? 1u : 0u;
-            }
-        }
-    }
-    uint32_t kth_bits = 0;
-    bool have_kth = false;
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-        const uint32_t c = r * 64 + lane;
-        if (c < cnt && rank[r] < kout) {
-            out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
-            out_score[(size_t)q * kout + rank[r]] = pref_score(cand_pref(e[r]), L2);
-        }
-        if (c < cnt && rank[r] == kout - 1) {
-            kth_bits = cand_pref(e[r]);
-            have_kth = true;
-        }
-    }
-    // margin proof (one lane holds the k-th best exact score)
-    bool bad = false;
-    if (have_kth && cnt == KP) {  // cnt < KP: every corpus vector is a candidate, nothing to prove
-        const float exact_k = pref_score(kth_bits, L2);
-        const float T = ord_f32(cand_pref(sel[(size_t)q * KP + KP - 1]));
+    for (int r = 0; r < RK; ++r) e[r] = 0;
+    auto exact = [&](uint32_t c) -> uint64_t {  // candidate c of this query, re-scored in the reference's order
+        const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
+        const float* col = V + i;
+        float acc = 0.0f;
         if (L2) {
-            // outsiders: approx <= T, i.e. their approximate distance C - approx >= C - T, exact >= C - T - E
-            const float Cq = qaux[q];
-            bad = !(exact_k < (Cq - T) - err_scale * Cq);
+#pragma unroll 8
+            for (uint32_t d = 0; d < D; ++d) {
+                const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
+                acc = ex::mad2(acc, diff, diff);
+            }
         } else {
-            const float E = eq ? eq[q] : (COS ? err_scale : err_scale * qn);  // eq: a per-query bound (int8 filter of an f32 corpus)
-            bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
+#pragma unroll 8
+            for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
         }
+        if (COS) {
+            const float vn = norms[i];
+            acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
+        }
+        return cand_make(score_pref<L2>(acc), i);
+    };
+    // rounds [0,32) [32,64) [64,128) [128,256): candidate c lives in slot c / 64 of lane c % 64
+    constexpr int NR = RK == 1 ? 2 : (RK == 2 ? 3 : 4);
+#pragma unroll
+    for (int round = 0; round < NR; ++round) {
+        const uint32_t lo = round == 0 ? 0u : (32u << (round - 1)), hi = 32u << round;
+        if (lo >= cnt && round > 0) break;  // (wave-uniform)
+        if (round < 2) {
+            const uint32_t c = (uint32_t)lane;
+            if (c >= lo && c < hi && c < cnt) e[0] = exact(c);
+        } else {
+#pragma unroll
+            for (int r = (round == 2 ? 1 : 2); r < (round == 2 ? 2 : 4); ++r)
+                if (r < RK) {
+                    const uint32_t c = (uint32_t)(r * 64 + lane);
+                    if (c < cnt) e[r < RK ? r : 0] = exact(c);
+                }
+        }
+        const uint32_t done = hi < cnt ? hi : cnt;
+        const bool last = done == cnt;
+        if (!last && (!early || done < kout)) continue;  // nothing to decide yet
+        uint32_t rank[RK];
+        rescore_rank<RK>(e, done, rank);
+        uint32_t kth_bits = 0;
+        bool have_kth = false;
+#pragma unroll
+        for (int r = 0; r < RK; ++r) {
+            const uint32_t c = r * 64 + lane;
+            if (c < done && rank[r] == kout - 1) {
+                kth_bits = cand_pref(e[r]);
+                have_kth = true;
+            }
+        }
+        // margin proof (one lane holds the k-th best exact score)
+        bool bad = false;
+        if (have_kth && (!last || cnt == KP)) {  // last round with cnt < KP: every corpus vector is a candidate, nothing to prove
+            const float exact_k = pref_score(kth_bits, L2);
+            // T: no candidate that has not been re-scored, and no vector outside the lists, has a better approximate score
+            const float T = ord_f32(cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]));
+            if (L2) {
+                // outsiders: approx <= T, i.e. their approximate distance C - approx >= C - T, exact >= C - T - E
+                const float Cq = qaux[q];
+                bad = !(exact_k < (Cq - T) - (eq ? eq[q] : err_scale * Cq));
+            } else {
+                const float E = eq ? eq[q] : (COS ? err_scale : err_scale * qn);  // eq: a per-query bound (int8 filter of an f32 corpus)
+                bad = !(exact_k > T + E);  // also true for NaN / inf arithmetic: those queries go to the exact engine
+            }
+        }
+        const bool failed = __any(bad);
+        if (failed && !last) continue;  // not proven yet: the next round brings more candidates
+#pragma unroll
+        for (int r = 0; r < RK; ++r) {
+            const uint32_t c = r * 64 + lane;
+            if (c < done && rank[r] < kout) {
+                out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
+                out_score[(size_t)q * kout + rank[r]] = pref_score(cand_pref(e[r]), L2);
+            }
+        }
+        if (failed && lane == 0) fallback[q] = 1;
+        return;
     }
-    if (__any(bad) && lane == 0) fallback[q] = 1;
 }
 
 // Re-rank support: composites for caller-given candidate indices (any order; duplicates allowed but pointless),

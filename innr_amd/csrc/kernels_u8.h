@@ -291,7 +291,8 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
                                                         const uint64_t* __restrict__ sel, const uint32_t* __restrict__ sel_cnt,
                                                         uint32_t KP, uint32_t kout, float err_scale, uint64_t index_base,
                                                         uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
-                                                        uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr) {
+                                                        uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr,
+                                                        bool early = false) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
@@ -299,56 +300,69 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
     const float qs = qsum[q];
     uint64_t e[RK];
 #pragma unroll
-    for (int r = 0; r < RK; ++r) {
-        const uint32_t c = r * 64 + lane;
-        e[r] = 0;
-        if (c < cnt) {
-            const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
-            const uint8_t* col = C + i;
-            float acc = -0.0f;
+    for (int r = 0; r < RK; ++r) e[r] = 0;
+    auto exact = [&](uint32_t c) -> uint64_t {
+        const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
+        const uint8_t* col = C + i;
+        float acc = -0.0f;
 #pragma unroll 8
-            for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], (float)col[(size_t)d * ldN]);
-            e[r] = cand_make(f32_ord(u8_score(a255, acc, offset, qs)), i);
+        for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], (float)col[(size_t)d * ldN]);
+        return cand_make(f32_ord(u8_score(a255, acc, offset, qs)), i);
+    };
+    // progressive rounds [0,32) [32,64) [64,128) [128,256), as in rescore_kernel (kernels_gemm.h)
+    constexpr int NR = RK == 1 ? 2 : (RK == 2 ? 3 : 4);
+#pragma unroll
+    for (int round = 0; round < NR; ++round) {
+        const uint32_t lo = round == 0 ? 0u : (32u << (round - 1)), hi = 32u << round;
+        if (lo >= cnt && round > 0) break;
+        if (round < 2) {
+            const uint32_t c = (uint32_t)lane;
+            if (c >= lo && c < hi && c < cnt) e[0] = exact(c);
+        } else {
+#pragma unroll
+            for (int r = (round == 2 ? 1 : 2); r < (round == 2 ? 2 : 4); ++r)
+                if (r < RK) {
+                    const uint32_t c = (uint32_t)(r * 64 + lane);
+                    if (c < cnt) e[r < RK ? r : 0] = exact(c);
+                }
         }
-    }
-    uint32_t rank[RK];
+        const uint32_t done = hi < cnt ? hi : cnt;
+        const bool last = done == cnt;
+        if (!last && (!early || done < kout)) continue;
+        uint32_t rank[RK];
+        rescore_rank<RK>(e, done, rank);
+        uint32_t kth_bits = 0;
+        bool have_kth = false;
 #pragma unroll
-    for (int r = 0; r < RK; ++r) rank[r] = 0;
-#pragma unroll
-    for (int r2 = 0; r2 < RK; ++r2) {
-        if ((uint32_t)(r2 * 64) < cnt) {
-            const int lim = (cnt - r2 * 64) < 64u ? (int)(cnt - r2 * 64) : 64;
-            for (int l = 0; l < lim; ++l) {
-                const uint64_t bcast = readlane_u64(e[r2], l);
-#pragma unroll
-                for (int r = 0; r < RK; ++r) rank[r] += (bcast > e[r]) ? 1u : 0u;
+        for (int r = 0; r < RK; ++r) {
+            const uint32_t c = r * 64 + lane;
+            if (c < done && rank[r] == kout - 1) {
+                kth_bits = cand_pref(e[r]);
+                have_kth = true;
             }
         }
-    }
-    uint32_t kth_bits = 0;
-    bool have_kth = false;
+        bool bad = false;
+        if (have_kth && (!last || cnt == KP)) {
+            const float exact_k = ord_f32(kth_bits);
+            const float T = ord_f32(cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]));
+            // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||  +  8u * |offset * sum(q)|
+            // eq[q] (int8 filter engine): the query's own share of the bound (its 16-bit quantisation), +inf = unprovable
+            const float E = err_scale * qnorm[q] + 4.8e-7f * fabsf(ex::mul(offset, qs)) + (eq ? eq[q] : 0.0f);
+            bad = !(exact_k > T + E);
+        }
+        const bool failed = __any(bad);
+        if (failed && !last) continue;
 #pragma unroll
-    for (int r = 0; r < RK; ++r) {
-        const uint32_t c = r * 64 + lane;
-        if (c < cnt && rank[r] < kout) {
-            out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
-            out_score[(size_t)q * kout + rank[r]] = ord_f32(cand_pref(e[r]));
+        for (int r = 0; r < RK; ++r) {
+            const uint32_t c = r * 64 + lane;
+            if (c < done && rank[r] < kout) {
+                out_idx[(size_t)q * kout + rank[r]] = index_base + cand_idx(e[r]);
+                out_score[(size_t)q * kout + rank[r]] = ord_f32(cand_pref(e[r]));
+            }
         }
-        if (c < cnt && rank[r] == kout - 1) {
-            kth_bits = cand_pref(e[r]);
-            have_kth = true;
-        }
+        if (failed && lane == 0) fallback[q] = 1;
+        return;
     }
-    bool bad = false;
-    if (have_kth && cnt == KP) {
-        const float exact_k = ord_f32(kth_bits);
-        const float T = ord_f32(cand_pref(sel[(size_t)q * KP + KP - 1]));
-        // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||  +  8u * |offset * sum(q)|
-        // eq[q] (int8 filter engine): the query's own share of the bound (its 16-bit quantisation), +inf = unprovable
-        const float E = err_scale * qnorm[q] + 4.8e-7f * fabsf(ex::mul(offset, qs)) + (eq ? eq[q] : 0.0f);
-        bad = !(exact_k > T + E);
-    }
-    if (__any(bad) && lane == 0) fallback[q] = 1;
 }
 
 // fused top-k variant (see kernels_scan.h scan_filter_kernel)

@@ -165,4 +165,24 @@ __device__ __forceinline__ uint32_t wave_compact(uint64_t* list, uint32_t cnt, u
     return keep;
 }
 
+// rank of every re-scored candidate among the first `done` of them (composite order = score desc, index asc); candidate c lives
+// in slot c / 64 of lane c % 64 (rescore_kernel, rescore_u8_kernel)
+template <int RK>
+__device__ __forceinline__ void rescore_rank(const uint64_t (&e)[RK], uint32_t done, uint32_t (&rank)[RK]) {
+#pragma unroll
+    for (int r = 0; r < RK; ++r) rank[r] = 0;
+#pragma unroll
+    for (int r2 = 0; r2 < RK; ++r2) {
+        if ((uint32_t)(r2 * 64) < done) {
+            const int lim = (done - r2 * 64) < 64u ? (int)(done - r2 * 64) : 64;
+            for (int l = 0; l < lim; ++l) {
+                const uint64_t bcast = readlane_u64(e[r2], l);
+#pragma unroll
+                for (int r = 0; r < RK; ++r) rank[r] += (bcast > e[r]) ? 1u : 0u;
+            }
+        }
+    }
+}
+
+
 }  // namespace innr

@@ -2420,7 +2420,11 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) {
         engine = innr_batch_auto_engine(b, Q);
-        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !getenv("INNR_U8_NO_I8")) engine = INNR_KNN_MFMA_I8;
+        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !getenv("INNR_U8_NO_I8")) {
+            // the int8 filter's smallest tile is 512 queries (46 ms at 50M x 768 whatever the batch size); the exact engine's
+            // 8-query passes cost 17.7 ms each there: two passes still win (profiles/r02_u8_exact_scan_50Mx768.txt)
+            engine = Q <= 16 ? INNR_KNN_EXACT : INNR_KNN_MFMA_I8;
+        }
     }
     if (engine == INNR_KNN_MFMA_BF16) engine = INNR_KNN_MFMA;  // codes are exact in 8 bits: the low-precision filter is the int8 one
     if (engine == INNR_KNN_MFMA_I8 && !i8_eligible(b, Q)) engine = INNR_KNN_MFMA;  // alpha <= 0 / non-finite params / D beyond the limbs

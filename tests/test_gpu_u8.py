@@ -177,6 +177,9 @@ def test_u8_engines_agree_large(S, innr):
         assert np.array_equal(i1[:32], i2) and bits_equal(s1[:32], s2)
         assert st.engine == (innr.KNN_MFMA_I8 if engine == innr.KNN_AUTO else engine)  # AUTO: the int8 filter
         print(f"u8 2Mx128 256q engine {st.engine}: gemm {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms fallback {st.queries_fallback}")
+    st = innr.KnnStats()
+    i1, s1 = qc.knn_multi(qs[:13], 10, engine=innr.KNN_AUTO, stats=st)  # up to 16 queries: two 8-query passes of the exact scan
+    assert st.engine == innr.KNN_EXACT and np.array_equal(i1, i2[:13]) and bits_equal(s1, s2[:13])
 
 
 def test_i8_engine_special_queries_and_params(S, innr):

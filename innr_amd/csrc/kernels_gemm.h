@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void gemm_filter_ke
     constexpr int kEpiTgWait = 8 + NP;  // gemm_epilogue.inc: at most this many VMEM ops of the wave are in flight at a tile end
     const float* V = static_cast<const float*>(Vraw);
     const uint8_t* C8 = static_cast<const uint8_t*>(Vraw);
-    constexpr int kGemmWaves = WAVES, kBQ = 64 * WAVES;
+    constexpr int kBQ = 64 * WAVES;
     __shared__ GemmLds<WAVES> s;
     constexpr uint32_t cap = 64 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -893,6 +893,12 @@ static innr_status check_errflag(innr_ctx* c) {
     uint32_t e = 0;
     INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
     INNR_HIP_CHECK(ctx_sync(c));
+    if (const char* pb = getenv("INNR_I8H_PROBE"); pb && (atoi(pb) & 4)) {  // tools/i8h_probe.py: the one-limb int8 kernel's visit counters
+        uint32_t h[12] = {0};
+        INNR_HIP_CHECK(hipMemcpyAsync(h, c->flags.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "i8h probe: wave epilogues that visit %u | survivors of the coarse test %u | appended %u\n", h[8], h[9], h[10]);
+    }
     if (e) {
         set_error("internal: candidate-list invariant violated (flag=%u)", e);
         return INNR_E_HIP;
@@ -2124,7 +2130,8 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     const bool two = p.two;
 #define INNR_I8_ARGS                                                                                                      \
     corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
-        c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump
+        c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump,                               \
+        (MODE == 0 && getenv("INNR_I8H_PROBE")) ? (size_t)atoi(getenv("INNR_I8H_PROBE")) : ld_dump
 #define INNR_I8_LAUNCH(RR)                                                                                                \
     do {                                                                                                                  \
         if (two) gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                  \

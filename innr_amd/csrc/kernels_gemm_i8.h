@@ -757,7 +757,11 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         const int32_t b23 = gbest[ct][2] > gbest[ct][3] ? gbest[ct][2] : gbest[ct][3];
                         hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
                     }
-                    if (__any(hit[0] || hit[1])) {
+                    // (MODE 0 has no use for ld_dump: INNR_I8H_PROBE passes probe bits there -- 1: never visit (timing only, wrong
+                    //  answers), 4: count visits / survivors / appends into errflag[8..10]; tools/i8h_probe.py)
+                    const bool probe = (ld_dump & 4) != 0;
+                    if (__any(hit[0] || hit[1]) && !(ld_dump & 1)) {
+                        if (probe && lane == 0) atomicAdd(errflag + 8, 1u);
                         unsigned long long admitted_by[2] = {0ull, 0ull};
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
@@ -793,6 +797,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                     unsigned long long mm = __ballot(sel_site >= 0);
                                     if (!mm) break;
                                     taken += sel_site >= 0 ? 1 : 0;
+                                    if (probe && lane == 0) atomicAdd(errflag + 9, (uint32_t)__popcll(mm));
                                     while (mm) {
                                         const int L = __builtin_ctzll(mm);
                                         mm &= mm - 1;
@@ -817,6 +822,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                             const uint32_t o = f32_ord(__builtin_fmaf(Aj[ct], (float)V, Bj[ct]));
                                             const size_t i = tb + 4 * (size_t)i_L + rtL;
                                             if (o >= thr[ct] && i < N) {
+                                                if (probe) atomicAdd(errflag + 10, 1u);
                                                 admitted = admitted || (((uint32_t)i & (kPubEvery - 1)) == 0);
                                                 cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
                                                 gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);

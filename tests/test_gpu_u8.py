@@ -182,6 +182,22 @@ def test_u8_engines_agree_large(S, innr):
     assert st.engine == innr.KNN_EXACT and np.array_equal(i1, i2[:13]) and bits_equal(s1, s2[:13])
 
 
+@pytest.mark.parametrize("n,dim,nq,k", [(300_000, 320, 600, 10), (200_000, 1024, 130, 100), (150_000, 256, 1030, 33)])
+def test_i8_engine_longer_rows_and_many_tiles(S, innr, n, dim, nq, k):
+    """4 to 16 K-steps of 64 dimensions per tile, several tiles per slice, lists of 64 / 128 / 256 (two limbs): the answers are
+    the exact engine's, bit for bit"""
+    p = S.QuantizationParams.from_range(-1.0, 1.0)
+    qc = S.QuantizedCorpus.generate(n, dim, p, seed=5)
+    qs = oracle.generate_uniform(nq, dim, 77)
+    st = innr.KnnStats()
+    i1, s1 = qc.knn_multi(qs, k, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8
+    i2, s2 = qc.knn_multi(qs[:64], k, engine=innr.KNN_EXACT)
+    assert np.array_equal(i1[:64], i2) and bits_equal(s1[:64], s2)
+    i3, s3 = qc.knn_multi(qs[-40:], k, engine=innr.KNN_EXACT)
+    assert np.array_equal(i1[-40:], i3) and bits_equal(s1[-40:], s3)
+
+
 def test_i8_engine_special_queries_and_params(S, innr):
     """zero / tiny / huge / non-finite queries and parameter sets the int8 limbs cannot represent: the answer is the
     oracle's in every case (unprovable queries take the exact engine; alpha <= 0 is served by the f32 GEMM engine)"""

@@ -15,7 +15,7 @@ import weakref
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libinnr_hip.so")
+LIB_PATH = os.environ.get("INNR_HIP_LIB_PATH") or os.path.join(_HERE, "lib", "libinnr_hip.so")  # (the override: A/B builds of tools/)
 
 OK = 0
 E_DIM_MISMATCH = -1

@@ -36,6 +36,14 @@ namespace innr {
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
+// The one-limb kernel re-derives a query's chip-wide bound for one admitted candidate in 32 (kPubEvery, topk_dev.h, says 4 for
+// the other kernels): a re-derivation loads the query's slots, and that wait sits out everything the wave has in flight. C2
+// shape, kernel ms (tools/i8h_ab.py over builds with -DINNR_I8H_PUB_EVERY): 1: 12.97, 2: 11.99, 4: 11.3-11.5, 8: 11.19, 16: 11.00,
+// 32: 10.73, 64: 10.89; C3: 43.2 -> 42.8.
+#ifndef INNR_I8H_PUB_EVERY
+#define INNR_I8H_PUB_EVERY 32
+#endif
+constexpr uint32_t kI8hPubEvery = INNR_I8H_PUB_EVERY;
 constexpr int kI8Stages = 8, kI8Lead = 2, kI8StageBytes = 8192, kI8Waves = 8, kI8K = 64, kI8BQ = 256;
 static_assert(kI8Stages == 8 && kI8Lead == 2, "the one-barrier-per-two-steps schedule is derived for an 8-stage ring and a 2-step register ring");
 
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                             const size_t i = tb + 4 * (size_t)i_L + rtL;
                                             if (o >= thr[ct] && i < N) {
                                                 if (probe) atomicAdd(errflag + 10, 1u);
-                                                admitted = admitted || (((uint32_t)i & (kPubEvery - 1)) == 0);
+                                                admitted = admitted || (((uint32_t)i & (kI8hPubEvery - 1)) == 0);
                                                 cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
                                                 gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
                                             }

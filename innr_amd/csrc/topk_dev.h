@@ -73,8 +73,11 @@ constexpr uint32_t kSlotMul = INNR_SLOT_MUL;
 // A visit of the append path re-derives the chip-wide bound of a query only when it admitted a candidate whose corpus
 // index is a multiple of kPubEvery (a power of two): one admission in kPubEvery, chosen by a property of the data, not of
 // the schedule. Every admission still raises its slot (gthr_raise), so nothing is lost, the published bound just lags.
+// A re-derivation loads the query's slots, and that wait sits out everything the wave has in flight (the corpus DMA six steps
+// ahead): on the fast pipes it is the expensive part of a visit. C2 shape, builds with -DINNR_PUB_EVERY (profiles/r02_metrics_*):
+// bf16 filter kernel 14.49 ms at 4, 13.58 at 16, 13.61 at 32; the f32 kernel does not notice (106.6 ms either way).
 #ifndef INNR_PUB_EVERY
-#define INNR_PUB_EVERY 4
+#define INNR_PUB_EVERY 16
 #endif
 constexpr uint32_t kPubEvery = INNR_PUB_EVERY;
 

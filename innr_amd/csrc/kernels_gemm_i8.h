@@ -36,7 +36,7 @@ namespace innr {
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
-// The one-limb kernel re-derives a query's chip-wide bound for one admitted candidate in 32 (kPubEvery, topk_dev.h, says 4 for
+// The one-limb kernel re-derives a query's chip-wide bound for one admitted candidate in 32 (kPubEvery, topk_dev.h, says 16 for
 // the other kernels): a re-derivation loads the query's slots, and that wait sits out everything the wave has in flight. C2
 // shape, kernel ms (tools/i8h_ab.py over builds with -DINNR_I8H_PUB_EVERY): 1: 12.97, 2: 11.99, 4: 11.3-11.5, 8: 11.19, 16: 11.00,
 // 32: 10.73, 64: 10.89; C3: 43.2 -> 42.8.
@@ -547,7 +547,10 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 // With one accumulator set per (row tile, query tile) a wave owns 64 queries again: block tile 128 rows x 512 queries, the
 // corpus streamed once per 512 queries, the bf16 kernel's operand reuse (an LDS fragment feeds 2 MFMAs, an L2 fragment 4).
 // =====================================================================================================================
-constexpr int kI8hBQ = 512, kI8hS = 6;
+#ifndef INNR_I8H_S
+#define INNR_I8H_S 6
+#endif
+constexpr int kI8hBQ = 512, kI8hS = INNR_I8H_S;
 
 struct alignas(16) GemmI8hLds {
     alignas(16) char A[kI8Stages * kI8StageBytes];

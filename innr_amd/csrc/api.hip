@@ -894,10 +894,14 @@ static innr_status check_errflag(innr_ctx* c) {
     INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
     INNR_HIP_CHECK(ctx_sync(c));
     if (const char* pb = getenv("INNR_I8H_PROBE"); pb && (atoi(pb) & 4)) {  // tools/i8h_probe.py: the one-limb int8 kernel's visit counters
-        uint32_t h[12] = {0};
+        uint32_t h[18] = {0};
         INNR_HIP_CHECK(hipMemcpyAsync(h, c->flags.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
-        fprintf(stderr, "i8h probe: wave epilogues that visit %u | survivors of the coarse test %u | appended %u\n", h[8], h[9], h[10]);
+        unsigned long long cv, cs, ct;
+        memcpy(&cv, h + 12, 8); memcpy(&cs, h + 14, 8); memcpy(&ct, h + 16, 8);
+        fprintf(stderr, "i8h probe: wave epilogues that visit %u | survivors of the coarse test %u | bound re-derivations %u | cycles per "
+                "visit %.0f, of them in the survivors' loops %.0f, publish + compaction %.0f\n", h[8], h[9], h[10],
+                h[8] ? (double)cv / h[8] : 0.0, h[8] ? (double)cs / h[8] : 0.0, h[8] ? (double)ct / h[8] : 0.0);
     }
     if (e) {
         set_error("internal: candidate-list invariant violated (flag=%u)", e);

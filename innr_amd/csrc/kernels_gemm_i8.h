@@ -670,6 +670,9 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
         for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
     }
     uint32_t tile = t0, ks = 0;
+    // INNR_I8H_PROBE bit 4 (tools/i8h_probe.py): per wave, flushed once at the end -- per-event atomics on one address slowed the kernel 5x
+    uint32_t pc_nvis = 0, pc_nsurv = 0, pc_npub = 0;
+    unsigned long long pc_visit = 0, pc_surv = 0, pc_tail = 0;  // cycles inside visits / inside the survivors' loops / publish + compaction
     for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
 #pragma unroll
         for (int r = 0; r < kI8Lead; ++r) {
@@ -769,10 +772,11 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
                     }
                     // (MODE 0 has no use for ld_dump: INNR_I8H_PROBE passes probe bits there -- 1: never visit (timing only, wrong
-                    //  answers), 4: count visits / survivors / appends into errflag[8..10]; tools/i8h_probe.py)
+                    //  answers), 4: count visits / survivors / bound re-derivations and the cycles they take into errflag[8..17]; tools/i8h_probe.py)
                     const bool probe = (ld_dump & 4) != 0;
                     if (__any(hit[0] || hit[1]) && !(ld_dump & 1)) {
-                        if (probe && lane == 0) atomicAdd(errflag + 8, 1u);
+                        const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
+                        pc_nvis += probe ? 1u : 0u;
                         unsigned long long admitted_by[2] = {0ull, 0ull};
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
@@ -808,7 +812,8 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                     unsigned long long mm = __ballot(sel_site >= 0);
                                     if (!mm) break;
                                     taken += sel_site >= 0 ? 1 : 0;
-                                    if (probe && lane == 0) atomicAdd(errflag + 9, (uint32_t)__popcll(mm));
+                                    pc_nsurv += probe ? (uint32_t)__popcll(mm) : 0u;
+                                    const unsigned long long ps0 = probe ? __builtin_readcyclecounter() : 0ull;
                                     while (mm) {
                                         const int L = __builtin_ctzll(mm);
                                         mm &= mm - 1;
@@ -833,17 +838,19 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                             const uint32_t o = f32_ord(__builtin_fmaf(Aj[ct], (float)V, Bj[ct]));
                                             const size_t i = tb + 4 * (size_t)i_L + rtL;
                                             if (o >= thr[ct] && i < N) {
-                                                if (probe) atomicAdd(errflag + 10, 1u);
                                                 admitted = admitted || (((uint32_t)i & (kI8hPubEvery - 1)) == 0);
                                                 cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
                                                 gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
                                             }
                                         }
                                     }
+                                    if (probe) pc_surv += __builtin_readcyclecounter() - ps0;
                                 }
                             }
                             admitted_by[ct] = __ballot(admitted);
+                            pc_npub += probe ? (uint32_t)__popcll(admitted_by[ct]) : 0u;
                         }
+                        const unsigned long long pt1 = probe ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
                             unsigned long long m = admitted_by[ct];
@@ -873,6 +880,11 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
+                        if (probe) {
+                            const unsigned long long pt2 = __builtin_readcyclecounter();
+                            pc_visit += pt2 - pt0;
+                            pc_tail += pt2 - pt1;
+                        }
                     }
                 }
                 if (MODE == 0) {
@@ -892,6 +904,14 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     }
     wait_all();
     __syncthreads();
+    if (MODE == 0 && (ld_dump & 4) && lane == 0) {
+        atomicAdd(errflag + 8, pc_nvis);
+        atomicAdd(errflag + 9, pc_nsurv);
+        atomicAdd(errflag + 10, pc_npub);
+        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 12), pc_visit);
+        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 14), pc_surv);
+        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 16), pc_tail);
+    }
     if (MODE == 0) {
         const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         unsigned long long need = __ballot(c > KP);

@@ -6,14 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import oracle
-from innr_amd import KNN_EXACT, KNN_MFMA, KNN_MFMA_BF16, KnnStats
+from innr_amd import KNN_EXACT, KNN_MFMA, KNN_MFMA_BF16, KNN_MFMA_I8, KnnStats
 from innr_amd import batch as B
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-ENGINE = KNN_MFMA_BF16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else KNN_MFMA  # python tools/stress_mfma.py 30 bf16
+ENGINE = {"bf16": KNN_MFMA_BF16, "i8": KNN_MFMA_I8}.get(sys.argv[2] if len(sys.argv) > 2 else "", KNN_MFMA)  # python tests/stress_mfma.py 30 bf16 | i8
 bad = 0
 shapes = [(10_000, 48, 70, 10), (40_000, 48, 70, 10), (3_333, 64, 300, 33), (200_000, 32, 40, 10), (1_000_000, 128, 256, 10),
-          (500_000, 96, 1024, 10), (300_000, 64, 600, 16)]  # the last two run on 8-wave blocks (Q > 256, k <= 16)
+          (500_000, 96, 1024, 10), (300_000, 64, 600, 16), (400_000, 320, 700, 10)]  # the last three run on 8-wave blocks (Q > 256, k <= 16)
 for (n, dim, nq, k) in shapes:
     vb = B.VerticalBatch.generate(n, dim, seed=7)
     qs = oracle.generate_uniform(nq, dim, 99)

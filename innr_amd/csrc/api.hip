@@ -889,6 +889,13 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     return INNR_OK;
 }
 
+// tools/i8h_probe.py: with bit 1 the one-limb int8 kernel never visits its append path -- what the K-loop and the fast reject cost
+// alone. Such a call fills its stats and then FAILS: a timing run must not hand out results.
+static bool i8h_probe_skips_visits() {
+    const char* pb = getenv("INNR_I8H_PROBE");
+    return pb && (atoi(pb) & 1);
+}
+
 static innr_status check_errflag(innr_ctx* c) {
     uint32_t e = 0;
     INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
@@ -1567,6 +1574,10 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
         stats->gemm_ms = gemm_ms;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
+    }
+    if (engine == INNR_KNN_MFMA_I8 && i8h_probe_skips_visits()) {
+        set_error("INNR_I8H_PROBE bit 1 is set: the int8 filter kernel skipped its visits, this call was a timing run and its results are not valid");
+        return INNR_E_UNSUPPORTED;
     }
     return INNR_OK;
 }
@@ -2462,6 +2473,10 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
         stats->gemm_ms = gemm_ms;
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
+    }
+    if (engine == INNR_KNN_MFMA_I8 && i8h_probe_skips_visits()) {
+        set_error("INNR_I8H_PROBE bit 1 is set: the int8 filter kernel skipped its visits, this call was a timing run and its results are not valid");
+        return INNR_E_UNSUPPORTED;
     }
     return INNR_OK;
 }

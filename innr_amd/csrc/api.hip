@@ -893,7 +893,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
 // alone. Such a call fills its stats and then FAILS: a timing run must not hand out results.
 static bool i8h_probe_skips_visits() {
     const char* pb = getenv("INNR_I8H_PROBE");
-    return pb && (atoi(pb) & 1);
+    return pb && (atoi(pb) & (1 | 8 | 16 | 32));  // (8, 16: the K-loop fed from L1 / L2 instead of its real operands)
 }
 
 static innr_status check_errflag(innr_ctx* c) {

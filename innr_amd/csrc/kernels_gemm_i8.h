@@ -552,10 +552,12 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 #endif
 constexpr int kI8hBQ = 512, kI8hS = INNR_I8H_S;
 
+constexpr int kI8hSurvCap = 128;  // survivors a wave queues before it finishes them (at least one round: 64)
 struct alignas(16) GemmI8hLds {
     alignas(16) char A[kI8Stages * kI8StageBytes];
     uint32_t cnt[kI8hBQ];
     uint32_t thr[kI8hBQ];
+    uint32_t surv[kI8Waves][kI8hSurvCap][4];  // a visit's survivors: high limb, corpus row, lane | query column tile << 8
 };
 
 // lo(i, q) = sum_d c'_d r2_d of corpus row `row_in_tile` of tile `tile` and query column q, from the packed arrays
@@ -627,18 +629,25 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     const uint32_t va = (uint32_t)lane * 16u;
     const uint32_t lds0 = lds_addr_uniform(&s.A[0]) + (uint32_t)wu * 1024u;
     // Bq[ks][kg][limb][Qpad][16]: depth m of a lane half h is kg = 2 m + h; only limb 0 feeds the matrix pipe
-    const size_t b_step = (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_ct = 32 * 16;
+    // (INNR_I8H_PROBE bit 8, timing only: every K-step reads the query fragments of step 0 -- they stay in the CU's L1)
+    const size_t b_step = (MODE == 0 && (ld_dump & 8)) ? 0 : (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_ct = 32 * 16;
     const char* sb = Bq + (q0 + (size_t)wu * 64) * 16;
     const uint32_t vb = ((uint32_t)half * 2u * (uint32_t)Qpad + (uint32_t)C) * 16u;
     uint32_t a_issued = 0, b_ks = 0;
     const uint32_t last = total ? total - 1 : 0;
     auto issue_a = [&]() {
-        const uint32_t st = a_issued < total ? a_issued : last;
+        // (INNR_I8H_PROBE bit 16, timing only: every DMA re-reads the slice's first stage -- the corpus stream comes from L2)
+        const uint32_t st = (MODE == 0 && (ld_dump & 16)) ? 0u : (a_issued < total ? a_issued : last);
         glds16(uniform_ptr(sa + (size_t)st * kI8StageBytes), va, lds0 + (a_issued % kI8Stages) * kI8StageBytes);
         ++a_issued;
     };
     auto issue_b = [&](u32x4_t& d0, u32x4_t& d1, int m) {
         const char* p = uniform_ptr(sb + (size_t)b_ks * b_step + (size_t)m * b_depth);
+        gload4(d0, p, vb);
+        gload4(d1, uniform_ptr(p + b_ct), vb);
+    };
+    auto issue_b_at = [&](u32x4_t& d0, u32x4_t& d1, int m, uint32_t kidx) {
+        const char* p = uniform_ptr(sb + (size_t)kidx * b_step + (size_t)m * b_depth);
         gload4(d0, p, vb);
         gload4(d1, uniform_ptr(p + b_ct), vb);
     };
@@ -725,6 +734,8 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                 dump[q * ld_dump + i] = __builtin_fmaf(Aj[ct], (float)V, Bj[ct]);
                             }
                     }
+                } else if (ld_dump & 32) {  // INNR_I8H_PROBE bit 32, timing only: no epilogue at all (the bare K-loop)
+                    use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
                 } else {
                     use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
                     uint32_t thr[2];
@@ -771,29 +782,97 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         const int32_t b23 = gbest[ct][2] > gbest[ct][3] ? gbest[ct][2] : gbest[ct][3];
                         hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
                     }
-                    // (MODE 0 has no use for ld_dump: INNR_I8H_PROBE passes probe bits there -- 1: never visit (timing only, wrong
+                    // (MODE 0 has no use for ld_dump: INNR_I8H_PROBE passes probe bits there -- 1: never visit, 8: query fragments from L1, 16: corpus stages from L2, 32: no epilogue (timing only, wrong
                     //  answers), 4: count visits / survivors / bound re-derivations and the cycles they take into errflag[8..17]; tools/i8h_probe.py)
                     const bool probe = (ld_dump & 4) != 0;
                     if (__any(hit[0] || hit[1]) && !(ld_dump & 1)) {
                         const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
                         pc_nvis += probe ? 1u : 0u;
-                        unsigned long long admitted_by[2] = {0ull, 0ull};
+                        // A visit borrows the K-loop's operand ring: once everything the wave has in flight has landed (the wait
+                        // a survivor's first load would sit out anyway), the ring's 32 registers hold nothing a visit needs -- its
+                        // fragments are requested again at the end -- and give the survivors' loads room to go out four
+                        // survivors at a time. (With registers of their own those loads pushed the ring into scratch, and
+                        // tools/check_gemm_asm.py refused the build.)
+#pragma unroll
+                        for (int r = 0; r < kI8Lead; ++r) {
+                            use_after<0>(breg[r][0], breg[r][1]);
+                            use_after<0>(breg[r][2], breg[r][3]);
+                        }
+                        asm volatile("; innr operand ring released" ::: "memory");
+                        // Phase 1: every lane queues its surviving sites (high limb, corpus row, lane and query column) in the wave's
+                        // LDS list -- in rounds: round r takes each lane's r-th survivor of a group of 16 sites (static register
+                        // indices, one compare + select per site), all lanes of a round write at once.
+                        // Phase 2 (flush): the queued survivors are finished FOUR per memory round trip. A survivor needs lo = the
+                        // dot of its corpus row with its query's low limb (nk * 4 chunks of 16 dimensions: a 16-byte load of
+                        // each, four v_dot4_i32_i8); quarter g of the wave computes the one of entry g, each of its 16 lanes
+                        // every 16th chunk with all its loads requested before the first is used, then a 4-step reduction; the
+                        // lane that owns the query runs the exact test and the append. One at a time a survivor cost 1 800
+                        // cycles, its own L2 round trip, and a visit has 6.5 of them, scattered over groups and rounds
+                        // (tools/i8h_probe.py) -- hence the list.
+                        uint32_t ns = 0;
+                        bool admitted[2] = {false, false};
+                        auto flush = [&]() {
+                            __builtin_amdgcn_wave_barrier();
+                            const unsigned long long ps0 = probe ? __builtin_readcyclecounter() : 0ull;
+                            const int g_mine = lane >> 4, l16 = lane & 15;
+                            for (uint32_t e0 = 0; e0 < ns; e0 += 4) {
+                                const uint32_t nb = ns - e0 < 4u ? ns - e0 : 4u;
+                                const uint32_t em = e0 + ((uint32_t)g_mine < nb ? (uint32_t)g_mine : 0u);
+                                const uint32_t hi_m = s.surv[wu][em][0], row_m = s.surv[wu][em][1], lc_m = s.surv[wu][em][2];
+                                const uint32_t rr = row_m - (uint32_t)tb;  // row inside the tile: 4 i_ + rt
+                                const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)tile * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
+                                const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (q0 + 64 * wu + 32 * ((lc_m >> 8) & 1u) + (lc_m & 31u));
+                                int32_t part = 0;
+                                for (uint32_t c0 = 0; c0 < nk * 4; c0 += 48) {  // 48 chunks (768 dimensions) per pass: three per lane
+                                    uint4 x[3], y[3];
+#pragma unroll
+                                    for (int t = 0; t < 3; ++t) {
+                                        const uint32_t c = c0 + (uint32_t)l16 + 16u * (uint32_t)t;
+                                        const bool on = (uint32_t)g_mine < nb && c < nk * 4;
+                                        x[t] = on ? pa[(size_t)c * 128] : uint4{0u, 0u, 0u, 0u};
+                                        y[t] = on ? pb[(size_t)c * 2 * Qpad] : uint4{0u, 0u, 0u, 0u};
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < 3; ++t) {
+                                        part = __builtin_amdgcn_sdot4((int)x[t].x, (int)y[t].x, part, false);
+                                        part = __builtin_amdgcn_sdot4((int)x[t].y, (int)y[t].y, part, false);
+                                        part = __builtin_amdgcn_sdot4((int)x[t].z, (int)y[t].z, part, false);
+                                        part = __builtin_amdgcn_sdot4((int)x[t].w, (int)y[t].w, part, false);
+                                    }
+                                }
+#pragma unroll
+                                for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+                                for (uint32_t g = 0; g < nb; ++g) {
+                                    const int32_t lo = __builtin_amdgcn_readlane(part, 16 * (int)g);
+                                    const int32_t hiL = (int32_t)__builtin_amdgcn_readlane((int)hi_m, 16 * (int)g);
+                                    const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)row_m, 16 * (int)g);
+                                    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)lc_m, 16 * (int)g);
+                                    const int L = (int)(lc & 63u);
+                                    const bool c1 = ((lc >> 8) & 1u) != 0;  // query column tile (wave-uniform)
+                                    const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)lo);
+                                    if (lane == L && V >= (c1 ? Tint[1] : Tint[0])) {
+                                        const uint32_t o = f32_ord(__builtin_fmaf(c1 ? Aj[1] : Aj[0], (float)V, c1 ? Bj[1] : Bj[0]));
+                                        if (o >= (c1 ? thr[1] : thr[0]) && i < N) {
+                                            const int ql = 64 * w + 32 * (c1 ? 1 : 0) + C;
+                                            const bool pub = (i & (kI8hPubEvery - 1)) == 0;
+                                            admitted[0] = admitted[0] || (pub && !c1);
+                                            admitted[1] = admitted[1] || (pub && c1);
+                                            cand_append(my_lists + (size_t)ql * cap, &s.cnt[ql], cap, cand_make(o, i), errflag);
+                                            gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, i);
+                                        }
+                                    }
+                                }
+                            }
+                            ns = 0;
+                            __builtin_amdgcn_wave_barrier();
+                            if (probe) pc_surv += __builtin_readcyclecounter() - ps0;
+                        };
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
-                            const int ql = 64 * w + 32 * ct + C;
-                            uint64_t* lq = my_lists + (size_t)ql * cap;
-                            bool admitted = false;
 #pragma unroll
                             for (int gq = 0; gq < 4; ++gq) {
                                 const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
                                 if (!__any(ghit)) continue;  // wave-uniform: most visits touch one group of one query column
-                                // Rounds: in round r every lane picks its r-th surviving site of this group (static register
-                                // indices, one compare + select per site), then the picked sites are finished ONE AT A TIME by
-                                // the whole wave: lane c computes chunk c of the low limb's dot (16 dimensions: one 16-byte load
-                                // of the site's corpus row and of the query's low limb, four v_dot4_i32_i8), a wave reduction
-                                // gives lo, the picking lane runs the exact test and the append. One memory round trip per
-                                // survivor instead of a 48-step dependent loop in a single lane -- and one copy of that code
-                                // per group, not per site (inlined per site it spilled the operand ring to scratch).
                                 int taken = 0;
                                 while (true) {
                                     int32_t sel_hi = 0;
@@ -809,47 +888,27 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                             sel_site = pick ? (4 * g3 + rt) : sel_site;
                                             seen += surv ? 1 : 0;
                                         }
-                                    unsigned long long mm = __ballot(sel_site >= 0);
+                                    const bool mine = sel_site >= 0;
+                                    const unsigned long long mm = __ballot(mine);
                                     if (!mm) break;
-                                    taken += sel_site >= 0 ? 1 : 0;
-                                    pc_nsurv += probe ? (uint32_t)__popcll(mm) : 0u;
-                                    const unsigned long long ps0 = probe ? __builtin_readcyclecounter() : 0ull;
-                                    while (mm) {
-                                        const int L = __builtin_ctzll(mm);
-                                        mm &= mm - 1;
-                                        const int32_t hiL = __builtin_amdgcn_readlane(sel_hi, L);
-                                        const uint32_t siteL = (uint32_t)__builtin_amdgcn_readlane(sel_site, L);
-                                        const uint32_t rtL = siteL & 3u, i_L = (siteL >> 2) + 8u * (uint32_t)gq + 4u * (uint32_t)(L >> 5);
-                                        const size_t qL = q0 + 64 * wu + 32 * ct + (L & 31);  // wave-uniform
-                                        const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)tile * nk * 4) * 128 + rtL * 32 + i_L;
-                                        const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + qL;
-                                        int32_t part = 0;
-                                        for (uint32_t c = (uint32_t)lane; c < nk * 4; c += 64) {
-                                            const uint4 x = pa[(size_t)c * 128], y = pb[(size_t)c * 2 * Qpad];
-                                            part = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, part, false);
-                                            part = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, part, false);
-                                            part = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, part, false);
-                                            part = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, part, false);
-                                        }
-#pragma unroll
-                                        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-                                        const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)part);
-                                        if (lane == L && V >= Tint[ct]) {
-                                            const uint32_t o = f32_ord(__builtin_fmaf(Aj[ct], (float)V, Bj[ct]));
-                                            const size_t i = tb + 4 * (size_t)i_L + rtL;
-                                            if (o >= thr[ct] && i < N) {
-                                                admitted = admitted || (((uint32_t)i & (kI8hPubEvery - 1)) == 0);
-                                                cand_append(lq, &s.cnt[ql], cap, cand_make(o, (uint32_t)i), errflag);
-                                                gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, (uint32_t)i);
-                                            }
-                                        }
+                                    taken += mine ? 1 : 0;
+                                    const uint32_t nm = (uint32_t)__popcll(mm);
+                                    pc_nsurv += probe ? nm : 0u;
+                                    if (ns + nm > (uint32_t)kI8hSurvCap) flush();
+                                    if (mine) {
+                                        const uint32_t slot = ns + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                                        const uint32_t site = (uint32_t)sel_site;
+                                        s.surv[wu][slot][0] = (uint32_t)sel_hi;
+                                        s.surv[wu][slot][1] = (uint32_t)tb + 4u * ((site >> 2) + 8u * (uint32_t)gq + 4u * (uint32_t)half) + (site & 3u);
+                                        s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
                                     }
-                                    if (probe) pc_surv += __builtin_readcyclecounter() - ps0;
+                                    ns += nm;
                                 }
                             }
-                            admitted_by[ct] = __ballot(admitted);
-                            pc_npub += probe ? (uint32_t)__popcll(admitted_by[ct]) : 0u;
                         }
+                        flush();
+                        unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
+                        pc_npub += probe ? (uint32_t)(__popcll(admitted_by[0]) + __popcll(admitted_by[1])) : 0u;
                         const unsigned long long pt1 = probe ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
@@ -880,6 +939,21 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
+                        // give the ring back: the fragments of the next two K-steps again (ring slot r holds K-step b_ks - 2 + r),
+                        // and nothing may be in flight when the K-loop's counted waits resume
+                        asm volatile("; innr operand ring reclaimed" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < kI8Lead; ++r) {
+                            const uint32_t kidx = (b_ks + 2u * nk - (uint32_t)kI8Lead + (uint32_t)r) % nk;
+                            issue_b_at(breg[r][0], breg[r][1], 0, kidx);
+                            issue_b_at(breg[r][2], breg[r][3], 1, kidx);
+                        }
+                        wait_all();
+#pragma unroll
+                        for (int r = 0; r < kI8Lead; ++r) {
+                            use_after<0>(breg[r][0], breg[r][1]);
+                            use_after<0>(breg[r][2], breg[r][3]);
+                        }
                         if (probe) {
                             const unsigned long long pt2 = __builtin_readcyclecounter();
                             pc_visit += pt2 - pt0;

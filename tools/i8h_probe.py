@@ -1,5 +1,5 @@
 """Where does the one-limb int8 filter kernel's time go? C2 shape, INNR_I8H_PROBE bits: 1 = the epilogue never visits (what the K-loop + fast reject cost; the call fills its
-stats and then fails: a timing run hands out no results), 4 = count visiting wave epilogues / survivors / appends (slows the kernel):
+stats and then fails: a timing run hands out no results), 8 / 16 (with 1) = the K-loop with its query fragments served from L1 / its corpus stages from L2, 32 = no epilogue at all, 4 = count visiting wave epilogues / survivors / appends (slows the kernel):
     python tools/i8h_probe.py
 """
 import os
@@ -25,6 +25,6 @@ for it in range(4):
         best = st
 print(f"INNR_I8H_PROBE={os.environ.get('INNR_I8H_PROBE', '0')}: kernel {best.gemm_ms:.3f} ms, call {best.total_ms:.3f} ms, redone {best.queries_fallback}")
 '''
-for bits in ("0", "1", "4"):
+for bits in ("0", "1", "9", "17", "25", "33", "57", "4"):
     env = dict(os.environ, INNR_I8H_PROBE=bits)
     subprocess.run([sys.executable, "-c", code], env=env, check=False)

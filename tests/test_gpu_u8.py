@@ -198,6 +198,23 @@ def test_i8_engine_longer_rows_and_many_tiles(S, innr, n, dim, nq, k):
     assert np.array_equal(i1[-40:], i3) and bits_equal(s1[-40:], s3)
 
 
+def test_i8_probe_run_hands_out_no_results(S, innr):
+    """INNR_I8H_PROBE bit 1 switches the int8 kernel's visits off to time its K-loop: such a call must fail, not return results"""
+    import os
+    p = S.QuantizationParams.from_range(-1.0, 1.0)
+    qc = S.QuantizedCorpus.generate(200_000, 256, p, seed=2)
+    qs = oracle.generate_uniform(600, 256, 3)
+    ref_i, ref_s = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
+    os.environ["INNR_I8H_PROBE"] = "1"
+    try:
+        with pytest.raises(innr.InnrError):
+            qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
+    finally:
+        del os.environ["INNR_I8H_PROBE"]
+    i2, s2 = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
+    assert np.array_equal(i2, ref_i) and bits_equal(s2, ref_s)
+
+
 def test_i8_engine_special_queries_and_params(S, innr):
     """zero / tiny / huge / non-finite queries and parameter sets the int8 limbs cannot represent: the answer is the
     oracle's in every case (unprovable queries take the exact engine; alpha <= 0 is served by the f32 GEMM engine)"""

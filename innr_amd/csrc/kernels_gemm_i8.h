@@ -541,7 +541,8 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 // hi = sum c' r1 runs on v_mfma_i32_32x32x32_i8; the low limb is BOUNDED in the fast reject,
 //     V = (hi << 6) + lo >= Tint   =>   hi >= (Tint - LOB_j) >> 6,     LOB_j = 128 sum_d |r2_d| >= |lo|,
 // and computed exactly (v_dot4_i32_i8 over the site's corpus row and the query's low limb, both read back from the packed
-// arrays) only for the sites that survive that test: ~1.6x the sites the full V would let through, a handful per tile. V is
+// arrays) only for the sites that survive that test: ~1.5x the sites the full V would let through -- queued in an LDS list per
+// wave and finished four per memory round trip on the K-loop's own operand-ring registers (see the epilogue). V is
 // then exact as before, so the candidates, the re-score and the proof are unchanged; the 14-bit query costs a 4x larger
 // quantisation bound than the 16-bit one (still ~1e-2 of the gap between neighbouring top scores at C3).
 // With one accumulator set per (row tile, query tile) a wave owns 64 queries again: block tile 128 rows x 512 queries, the

@@ -2222,7 +2222,8 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
                                                               (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
-                                                              d_out_score, fallback, qc + 3 * p.Qpad, !getenv("INNR_RESCORE_ALL"))
+                                                              d_out_score, fallback, qc + 3 * p.Qpad, !getenv("INNR_RESCORE_ALL"),  \
+                                                              reinterpret_cast<const uint4*>(b->Ai8), b->ai8_nk)
     if (p.KP <= 64) INNR_RESCORE_U8(1);
     else if (p.KP <= 128) INNR_RESCORE_U8(2);
     else INNR_RESCORE_U8(4);

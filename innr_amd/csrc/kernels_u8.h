@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
                                                         uint32_t KP, uint32_t kout, float err_scale, uint64_t index_base,
                                                         uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                         uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr,
-                                                        bool early = false) {
+                                                        bool early = false, const uint4* __restrict__ Ai8 = nullptr, uint32_t nk = 0) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
@@ -303,10 +303,26 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
     for (int r = 0; r < RK; ++r) e[r] = 0;
     auto exact = [&](uint32_t c) -> uint64_t {
         const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
-        const uint8_t* col = C + i;
         float acc = -0.0f;
+        if (Ai8) {
+            // The int8 engine's K-packed copy (kernels_gemm_i8.h: row 128 tile + 4 i_ + rt, 16 consecutive dimensions per 16-byte
+            // unit, c - 128 as i8) holds the same codes ROW-WISE: 16 codes per memory transaction instead of one -- a column
+            // gather of 768 single bytes is 768 sectors of 32 B per candidate (C3: 2.1 ms for 128 x 1024 candidates).
+            const uint4* rowp = Ai8 + ((size_t)(i >> 7) * nk * 4) * 128 + (i & 3u) * 32 + ((i & 127u) >> 2);
+            for (uint32_t ch = 0; ch * 16 < D; ++ch) {
+                const uint4 v = rowp[(size_t)ch * 128];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t d = ch * 16 + e;
+                    if (d < D) acc = ex::mad2(acc, qv[d], (float)(((w[e >> 2] >> (8 * (e & 3))) & 0xffu) ^ 0x80u));
+                }
+            }
+        } else {
+            const uint8_t* col = C + i;
 #pragma unroll 8
-        for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], (float)col[(size_t)d * ldN]);
+            for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], (float)col[(size_t)d * ldN]);
+        }
         return cand_make(f32_ord(u8_score(a255, acc, offset, qs)), i);
     };
     // progressive rounds [0,32) [32,64) [64,128) [128,256), as in rescore_kernel (kernels_gemm.h)

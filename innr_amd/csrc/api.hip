@@ -725,6 +725,17 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nre
     return INNR_OK;
 }
 
+// rows of the corpus prefix whose exact top-KP seeds the chip-wide thresholds (INNR_GEMM_SEED_N overrides: tools/seed_ab.py)
+// C2 shape, whole call (tools/seed_ab.py): int8 filter 13.50 / 12.80 / 12.38 / 12.12 / 12.59 ms at 512 / 1024 / 2048 / 4096 / 8192 rows
+// (without seeds 17.5), bf16 filter 16.14 -> 16.00 at 4096; the f32 kernel, whose visits are cheap next to its MFMAs, 107.37 / 107.42 /
+// 107.72 at 2048 / 4096 / 8192: the fast pipes take 4096 rows, the f32 pipe 2048.
+// (The seeding scan costs Q x rows: at 4096 queries the C5 shape went 41.2 -> 43.3 ms with 4096 rows, so larger batches keep 2048.)
+static size_t seed_prefix_rows(bool fast_pipe, size_t Q) {
+    const char* e = getenv("INNR_GEMM_SEED_N");
+    const long v = e ? atol(e) : 0;
+    return v >= 256 ? (size_t)v : (size_t)((fast_pipe && Q <= 2048) ? 4096 : 2048);
+}
+
 static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* /*dQn*/,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
                             float* gemm_ms, bool bf16, uint32_t kp_force, int level) {
@@ -796,7 +807,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
 
     // threshold seeding from the exact top-KP of a corpus prefix (seed_thresholds_kernel)
     const uint32_t* seed = nullptr;
-    constexpr size_t kSeedN = 2048;
+    const size_t kSeedN = seed_prefix_rows(use_bf16, Q);
     if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
         INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
         INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
@@ -2201,7 +2212,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     // threshold seeding (cf. knn_mfma): the exact top-KP of a 2048-document prefix per query; their KP-th exact score
     // lowered by the query's error bound is a valid chip-wide bound from the first tile on
     const uint32_t* seed = nullptr;
-    constexpr size_t kSeedN = 2048;
+    const size_t kSeedN = seed_prefix_rows(true, Q);
     if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
         INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
         INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
@@ -2371,7 +2382,7 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
     const uint32_t* seed = nullptr;
-    constexpr size_t kSeedN = 2048;
+    const size_t kSeedN = seed_prefix_rows(true, Q);
     if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
         INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
         INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));

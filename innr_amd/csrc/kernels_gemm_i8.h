@@ -38,7 +38,7 @@ typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
 // The one-limb kernel re-derives a query's chip-wide bound for one admitted candidate in 32 (kPubEvery, topk_dev.h, says 16 for
 // the other kernels): a re-derivation loads the query's slots, and that wait sits out everything the wave has in flight. C2
-// shape, kernel ms (tools/i8h_ab.py over builds with -DINNR_I8H_PUB_EVERY): 1: 12.97, 2: 11.99, 4: 11.3-11.5, 8: 11.19, 16: 11.00,
+// shape, kernel ms (tools/lib_ab.py over builds with -DINNR_I8H_PUB_EVERY): 1: 12.97, 2: 11.99, 4: 11.3-11.5, 8: 11.19, 16: 11.00,
 // 32: 10.73, 64: 10.89; C3: 43.2 -> 42.8.
 #ifndef INNR_I8H_PUB_EVERY
 #define INNR_I8H_PUB_EVERY 32

@@ -7,6 +7,7 @@ imported from here.)
 from __future__ import annotations
 
 import atexit
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -70,6 +71,8 @@ SIGNATURES = {
     "innr_ctx_destroy": (None, [_vp]),
     "innr_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "innr_ctx_synchronize": (C.c_int, [_vp]),
+    "innr_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_long]),
+    "innr_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_long)]),
     "innr_last_error": (C.c_char_p, []),
     "innr_version": (C.c_char_p, []),
     "innr_batch_upload_colmajor": (C.c_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
@@ -239,6 +242,25 @@ class Context:
 
     def synchronize(self) -> None:
         check(load().innr_ctx_synchronize(self.handle))
+
+    def set_option(self, name: str, value: int) -> None:
+        """A tuning / experiment switch of this context (include/innr_hip.h: innr_ctx_set_option). Never changes a result."""
+        check(load().innr_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long(0)
+        check(load().innr_ctx_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    @contextlib.contextmanager
+    def option(self, name: str, value: int):
+        """`with ctx.option("i8_two_limb", 1): ...` -- set for the block, restored afterwards."""
+        old = self.get_option(name)
+        self.set_option(name, value)
+        try:
+            yield
+        finally:
+            self.set_option(name, old)
 
     def close(self) -> None:
         """Free every batch created on this context, then the context (a batch must not outlive its ctx)."""

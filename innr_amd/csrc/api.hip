@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" boundary (include/innr_hip.h) over the gfx950 kernels.
 #include <dlfcn.h>
+#include <ctype.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -68,7 +69,44 @@ struct DevBuf {
 
 using namespace innr;
 
+// Tuning / experiment switches of a context. Read from the environment ONCE, in innr_ctx_create (INNR_<NAME IN CAPITALS>), and
+// changed afterwards only through innr_ctx_set_option: no entry point reads the environment on the call path.
+struct innr_tuning {
+    long gemm_waves = 0;         // force the f32 GEMM engine's block shape (1, 2, 4, 8 waves); 0 = by batch size
+    long gemm_blocks_per_cu = 0; // resident blocks per CU of the f32 GEMM engine; 0 = by block shape
+    long gemm_qt_group = 1;      // query tiles per XCD group (plan_gemm)
+    long gemm_seed_n = 0;        // rows of the corpus prefix that seeds the chip-wide bounds; 0 = by engine
+    long gemm_no_seed = 0;       // no threshold seeding
+    long gemm_no_kp_retry = 0;   // unproven minority: straight to the exact engine, no second pass with longer lists
+    long i8_two_limb = 0;        // batch_knn_u8 on the int8 pipe: both limbs on the matrix pipe (the cross-check kernel)
+    long no_auto_bf16 = 0;       // INNR_KNN_AUTO never picks the bf16 filter
+    long no_auto_i8 = 0;         // INNR_KNN_AUTO never picks the int8 filter for an f32 corpus
+    long u8_no_i8 = 0;           // INNR_KNN_AUTO never picks the int8 engine for a code corpus
+    long rescore_all = 0;        // re-score every candidate (no progressive rounds)
+    long maxsim_generic = 0;     // maxsim MFMA engine: the generic kernel instead of the tile-unrolled one
+    long no_k_rule = 0;          // chip-wide bounds by the KP rule only (topk_dev.h): A/B of the k rule
+};
+struct TuneName { const char* name; long innr_tuning::*field; };
+static const TuneName kTuneNames[] = {
+    {"gemm_waves", &innr_tuning::gemm_waves}, {"gemm_blocks_per_cu", &innr_tuning::gemm_blocks_per_cu},
+    {"gemm_qt_group", &innr_tuning::gemm_qt_group}, {"gemm_seed_n", &innr_tuning::gemm_seed_n},
+    {"gemm_no_seed", &innr_tuning::gemm_no_seed}, {"gemm_no_kp_retry", &innr_tuning::gemm_no_kp_retry},
+    {"i8_two_limb", &innr_tuning::i8_two_limb}, {"no_auto_bf16", &innr_tuning::no_auto_bf16},
+    {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
+    {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
+};
+static void tuning_from_env(innr_tuning* t) {
+    for (const TuneName& n : kTuneNames) {
+        char env[64] = "INNR_";
+        size_t o = 5;
+        for (const char* p = n.name; *p && o + 1 < sizeof(env); ++p) env[o++] = (char)toupper((unsigned char)*p);
+        env[o] = 0;
+        if (const char* e = getenv(env)) t->*(n.field) = atol(e);
+    }
+}
+
 struct innr_ctx {
+    innr_tuning tune;
     // One call at a time per context: the workspace below (grow-by-free DevBufs, the pinned bump allocator, `pending`,
     // the flags buffer, ev[]) is shared by every entry point, so each one holds this lock for its whole duration
     // (CtxGuard). Recursive: host-pointer entry points call their _dev counterparts.
@@ -99,7 +137,8 @@ struct innr_ctx {
     DevBuf counts;    // list counts
     DevBuf sel;       // selected composites [Q][KP]
     DevBuf sel_cnt;   // [Q]
-    DevBuf gthr;           // GEMM engine: global threshold slots + bounds
+    DevBuf gthr;           // GEMM engine: global threshold slots + bounds + k-rule margins
+    DevBuf kmargin;        // [Qpad] 2E per query, staged for prep_gthr
     DevBuf sel_tmp[2];     // multi-level select: [parts][Q][KP]
     DevBuf selcnt_tmp[2];  // [parts][Q]
     DevBuf scores;    // [QB][ldN] materialised scores
@@ -466,6 +505,59 @@ static innr_status close_padding_queries(innr_ctx* c, uint32_t* gthr, size_t nre
     return INNR_OK;
 }
 
+// Chip-wide threshold state of one GEMM-type launch (topk_dev.h): [Qpad][kSlotMul * KP] slots and [Qpad] bounds, zeroed for every
+// launch (the bounds then seeded / closed for padding queries), followed by [Qpad] floats: the k rule's margin 2E per query
+// (kmargin == null or kk == 0: +inf, the rule is off).
+static innr_status prep_gthr(innr_ctx* c, size_t Qpad, uint32_t KP, const uint32_t* seed, size_t nreal_q, const float* kmargin,
+                             uint32_t** gslots, size_t* nslot_out) {
+    const size_t nslot = Qpad * (size_t)kSlotMul * KP;
+    INNR_TRY(c->gthr.ensure((nslot + 2 * Qpad) * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, (nslot + Qpad) * sizeof(uint32_t), c->stream));
+    uint32_t* gs = c->gthr.as<uint32_t>();
+    if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gs + nslot, seed, Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    INNR_TRY(close_padding_queries(c, gs + nslot, nreal_q, Qpad));
+    if (kmargin) INNR_HIP_CHECK(hipMemcpyAsync(gs + nslot + Qpad, kmargin, Qpad * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    else INNR_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(gs + nslot + Qpad), 0x7f800000, Qpad, c->stream));
+    *gslots = gs;
+    *nslot_out = nslot;
+    return INNR_OK;
+}
+// the final bounds of the last launch's queries (what the re-score proves against)
+static const uint32_t* gthr_bounds(const innr_ctx* c, size_t Qpad, uint32_t KP) { return c->gthr.as<uint32_t>() + Qpad * (size_t)kSlotMul * KP; }
+
+// E per query by kind -> the k rule's margin 2E (+ rounding room); +inf where E is not finite and for padding queries.
+// kind 0: err_scale * qnorm[j] (dot), 1: err_scale (cosine), 2: err_scale * aux[j] (squared L2 in score space, aux = C_j),
+// 3: eq[j] (int8 filter of an f32 corpus), 4: err_scale * qnorm[j] + 4.8e-7 |offset * qsum[j]| + eq[j] (code corpus; eq nullable)
+__global__ void kmargin_kernel(int kind, float err_scale, const float* __restrict__ qnorm, const float* __restrict__ aux,
+                               const float* __restrict__ eq, float offset, const float* __restrict__ qsum, uint32_t Q, uint32_t Qpad,
+                               float* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Qpad) return;
+    float m = __builtin_inff();
+    if (j < Q) {
+        float E;
+        if (kind == 0) E = err_scale * qnorm[j];
+        else if (kind == 1) E = err_scale;
+        else if (kind == 2) E = err_scale * aux[j];
+        else if (kind == 3) E = eq[j];
+        else E = err_scale * qnorm[j] + 4.8e-7f * fabsf(offset * qsum[j]) + (eq ? eq[j] : 0.0f);
+        const float x = 2.0f * E * 1.0002f;
+        if (x - x == 0.0f && x >= 0.0f) m = x;
+    }
+    out[j] = m;
+}
+static innr_status make_kmargin(innr_ctx* c, int kind, float err_scale, const float* qnorm, const float* aux, const float* eq,
+                                float offset, const float* qsum, size_t Q, size_t Qpad, const float** out) {
+    *out = nullptr;
+    if (c->tune.no_k_rule) return INNR_OK;
+    INNR_TRY(c->kmargin.ensure(Qpad * sizeof(float)));
+    kmargin_kernel<<<(unsigned)((Qpad + 255) / 256), 256, 0, c->stream>>>(kind, err_scale, qnorm, aux, eq, offset, qsum, (uint32_t)Q,
+                                                                          (uint32_t)Qpad, c->kmargin.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    *out = c->kmargin.as<float>();
+    return INNR_OK;
+}
+
 struct GemmPlan {
     size_t Qpad;
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, waves;
@@ -483,10 +575,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
     // tile -- at 64 queries the f32 MFMA time (6.2 ms at C2) and the corpus stream (5.2 ms) are balanced.
     if (!b->C8 && Q <= 64) p.waves = 1u;
     else if (!b->C8 && Q <= 128) p.waves = 2u;
-    if (const char* e = getenv("INNR_GEMM_WAVES")) {
-        const int w = atoi(e);
-        if (w == 8 || w == 4 || ((w == 2 || w == 1) && !b->C8)) p.waves = (uint32_t)w;
-    }
+    if (const long w = b->ctx->tune.gemm_waves; w == 8 || w == 4 || ((w == 2 || w == 1) && !b->C8)) p.waves = (uint32_t)w;
     if (force_waves) p.waves = force_waves;
     const size_t bq = 64 * p.waves;
     p.Qpad = round_up(Q, bq);
@@ -496,7 +585,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
     const uint32_t ntiles = (uint32_t)(b->ldN / kBC);
     // resident blocks per CU: 8 waves' worth by registers, but never more blocks than SIMDs
     uint32_t per_cu = std::min(8u / p.waves, 4u);  // 1-wave blocks: one per SIMD (measured 4 / 5 / 6 per CU: 9.96 / 13.6 / 11.8 ms at Q = 64, C2)
-    if (const char* e = getenv("INNR_GEMM_BLOCKS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(atoi(e), 8));
+    if (const long v = b->ctx->tune.gemm_blocks_per_cu; v > 0) per_cu = (uint32_t)std::min<long>(v, 8);
     uint32_t target = (uint32_t)(per_cu * b->ctx->num_cus) / p.nqt;
     uint32_t ns = std::max(8u, target / 8 * 8);
     ns = std::min(ns, (uint32_t)round_up(ntiles, 8));
@@ -509,7 +598,7 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
     // group, 130 GB with 2, 191 GB with 4 -- blocks that share a slice drift further apart than a 4 MB L2 can
     // bridge, so co-locating query tiles buys no corpus reuse and only evicts queries. Same speed either way.
     uint32_t want = 1;
-    if (const char* e = getenv("INNR_GEMM_QT_GROUP")) want = (uint32_t)std::max(1, atoi(e));
+    if (const long v = b->ctx->tune.gemm_qt_group; v > 1) want = (uint32_t)v;
     p.qtg = p.nqt;
     for (uint32_t g = std::min(want, p.nqt); g <= p.nqt; ++g)
         if (p.nqt % g == 0 && 8 % (p.nqt / g) == 0) {
@@ -521,24 +610,21 @@ static GemmPlan plan_gemm(const innr_batch* b, size_t Q, size_t kout, uint32_t f
 
 template <int KIND, int MODE>
 static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, size_t nreal_q, const float* Qt, const float* invn, const float* invq,
-                               float* dump, size_t ld_dump, const uint32_t* seed = nullptr) {
+                               float* dump, size_t ld_dump, const uint32_t* seed = nullptr, const float* kmargin = nullptr,
+                               uint32_t kk = 0) {
     innr_ctx* c = b->ctx;
     uint64_t* lists = c->lists.as<uint64_t>();
     uint32_t* counts = c->counts.as<uint32_t>();
     uint32_t* err = c->flags.as<uint32_t>();
-    // chip-wide threshold state: [Qpad][KP] slots followed by [Qpad] bounds, zeroed for every launch
-    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
-    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
-    INNR_TRY(c->gthr.ensure(gbytes));
-    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
-    uint32_t* gslots = c->gthr.as<uint32_t>();
-    if (seed)  // initial chip-wide bounds (see seed_thresholds_kernel): valid lower bounds, the slots start empty as usual
-        INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
+    // chip-wide threshold state; seed: initial bounds (see seed_thresholds_kernel), valid lower bounds, the slots start empty as usual
+    uint32_t* gslots = nullptr;
+    size_t nslot = 0;
+    if (!kmargin) kk = 0;
+    INNR_TRY(prep_gthr(c, p.Qpad, p.KP, seed, nreal_q, kmargin, &gslots, &nslot));
 #define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
     gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
-        p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, err, gslots, gslots + nslot, dump,   \
+        p.nqt, p.qtg, p.tps, invn, invq, b->alpha / 255.0f, lists, counts, p.KP, kk, err, gslots, gslots + nslot, dump,   \
         ld_dump)
     // the 8-, 2- and 1-wave tiles exist for the product path only (MODE 0; the narrow ones not for the u8 kind); the
     // layout-dump hook stays on 4 waves
@@ -700,20 +786,18 @@ static innr_status ensure_bf16_corpus(innr_batch* b, int variant) {
     return INNR_OK;
 }
 
-static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed, int variant) {
+static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nreal_q, const uint32_t* seed, int variant,
+                                    const float* kmargin = nullptr, uint32_t kk = 0) {
     innr_ctx* c = b->ctx;
-    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
-    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
-    INNR_TRY(c->gthr.ensure(gbytes));
-    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
-    uint32_t* gslots = c->gthr.as<uint32_t>();
-    if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
+    uint32_t* gslots = nullptr;
+    size_t nslot = 0;
+    if (!kmargin) kk = 0;
+    INNR_TRY(prep_gthr(c, p.Qpad, p.KP, seed, nreal_q, kmargin, &gslots, &nslot));
 #define INNR_BF16_LAUNCH(RR)                                                                                              \
     gemm_bf16_filter_kernel<RR, 0><<<p.nblocks, 64 * kBfWaves, 0, c->stream>>>(                                             \
         variant == kBfCos ? b->Abn : (variant == kBfL2 ? b->Abl : b->Ab), c->q_bf16.as<char>(), (uint32_t)(b->ldN / 128), (uint32_t)b->N, \
         variant == kBfL2 ? b->abl_nk : b->ab_nk, p.Qpad, p.nqt, p.qtg, p.tps,                                                  \
-        c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, nullptr, 0)
+        c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot, nullptr, 0)
     switch (p.cap) {
         case 384: INNR_BF16_LAUNCH(6); break;
         case 512: INNR_BF16_LAUNCH(8); break;
@@ -730,9 +814,8 @@ static innr_status launch_gemm_bf16(innr_batch* b, const GemmPlan& p, size_t nre
 // (without seeds 17.5), bf16 filter 16.14 -> 16.00 at 4096; the f32 kernel, whose visits are cheap next to its MFMAs, 107.37 / 107.42 /
 // 107.72 at 2048 / 4096 / 8192: the fast pipes take 4096 rows, the f32 pipe 2048.
 // (The seeding scan costs Q x rows: at 4096 queries the C5 shape went 41.2 -> 43.3 ms with 4096 rows, so larger batches keep 2048.)
-static size_t seed_prefix_rows(bool fast_pipe, size_t Q) {
-    const char* e = getenv("INNR_GEMM_SEED_N");
-    const long v = e ? atol(e) : 0;
+static size_t seed_prefix_rows(const innr_ctx* c, bool fast_pipe, size_t Q) {
+    const long v = c->tune.gemm_seed_n;
     return v >= 256 ? (size_t)v : (size_t)((fast_pipe && Q <= 2048) ? 4096 : 2048);
 }
 
@@ -807,16 +890,18 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
 
     // threshold seeding from the exact top-KP of a corpus prefix (seed_thresholds_kernel)
     const uint32_t* seed = nullptr;
-    const size_t kSeedN = seed_prefix_rows(use_bf16, Q);
-    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
-        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
-        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
-        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, p.KP, c->seed_idx.as<uint64_t>(),
+    const size_t kSeedN = seed_prefix_rows(c, use_bf16, Q);
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
+        // k rule (topk_dev.h): the prefix's k-th best exact score, less E, already bounds the corpus' top k; KP rule: its KP-th
+        const uint32_t kseed = c->tune.no_k_rule ? p.KP : (uint32_t)kout;
+        INNR_TRY(c->seed_idx.ensure(Q * kseed * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * kseed * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, kseed, c->seed_idx.as<uint64_t>(),
                                  c->seed_score.as<float>(), ScanExt(), kSeedN));
-        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * kseed);
         seed_thresholds_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(
-            c->seed_score.as<float>(), (uint32_t)Q, p.KP, l2 ? 2 : (cos ? 1 : 0), err_scale, c->q_norm.as<float>(), Cj, sd,
-            (uint32_t)p.Qpad);
+            c->seed_score.as<float>(), (uint32_t)Q, kseed, l2 ? 2 : (cos ? 1 : 0), err_scale, c->q_norm.as<float>(), Cj, sd,
+            (uint32_t)p.Qpad, kseed - 1);
         INNR_HIP_CHECK(hipGetLastError());
         seed = sd;
         // the exact engine used the shared list / selection workspace: size it for the GEMM pass again
@@ -826,13 +911,17 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
         INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
     }
 
+    // the k rule of topk_dev.h: 2E per query, in the score space of the kind
+    const float* kmargin = nullptr;
+    INNR_TRY(make_kmargin(c, l2 ? 2 : (cos ? 1 : 0), err_scale, c->q_norm.as<float>(), Cj, nullptr, 0.0f, nullptr, Q, p.Qpad, &kmargin));
+    const uint32_t kk = (uint32_t)kout;
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed, bfv));
-    else if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed)));
-    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, Q, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed)));
+    if (use_bf16) INNR_TRY(launch_gemm_bf16(b, p, Q, seed, bfv, kmargin, kk));
+    else if (cos) INNR_TRY((launch_gemm<kGemmCos, 0>(b, p, Q, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, seed, kmargin, kk)));
+    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 0>(b, p, Q, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, seed, kmargin, kk)));
     // (A first pass of the same kernel over 1/16 of the corpus, only to harvest tighter bounds for the full pass, was
     //  tried: 17.6 ms for both against 16.4 for the single pass.)
-    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed)));
+    else INNR_TRY((launch_gemm<kGemmDot, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, seed, kmargin, kk)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
 
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
@@ -843,7 +932,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
                                                                  c->q_norm.as<float>(), Cj, c->sel.as<uint64_t>(),  \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout,   \
                                                                  err_scale, b->index_base, d_out_idx, d_out_score,  \
-                                                                 fallback, nullptr, !getenv("INNR_RESCORE_ALL"))
+                                                                 fallback, nullptr, !c->tune.rescore_all, gthr_bounds(c, p.Qpad, p.KP))
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
         if (rk == 1) INNR_RESCORE(1, 1); else if (rk == 2) INNR_RESCORE(1, 2); else INNR_RESCORE(1, 4);
@@ -882,7 +971,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
             // queries go through the f32 GEMM engine as one batch (its own proof, and the exact engine behind it).
             via = pick_kp(kout, 16);
         } else if (!use_bf16 && !kp_force && p.KP < 256 && redo.size() >= 16 && redo.size() * 4 <= Q &&
-                   !getenv("INNR_GEMM_NO_KP_RETRY")) {
+                   !c->tune.gemm_no_kp_retry) {
             // A minority of the batch failed: isolated clusters of near-equal scores (duplicates, quantised data), which
             // lists of 256 candidates usually swallow -- one more GEMM pass over those queries instead of an exact scan
             // for each 8 of them. When most of the batch fails the data is degenerate (the reference example's LCG
@@ -900,18 +989,18 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
     return INNR_OK;
 }
 
-// tools/i8h_probe.py: with bit 1 the one-limb int8 kernel never visits its append path -- what the K-loop and the fast reject cost
-// alone. Such a call fills its stats and then FAILS: a timing run must not hand out results.
-static bool i8h_probe_skips_visits() {
-    const char* pb = getenv("INNR_I8H_PROBE");
-    return pb && (atoi(pb) & (1 | 8 | 16 | 32));  // (8, 16: the K-loop fed from L1 / L2 instead of its real operands)
+// tools/i8h_probe.py (builds with -DINNR_I8H_PROBE=<bits>, never the product library): with bit 1 the one-limb int8 kernel never
+// visits its append path -- what the K-loop and the fast reject cost alone. Such a call fills its stats and then FAILS: a timing
+// run must not hand out results.
+static constexpr bool i8h_probe_skips_visits() {
+    return (kI8hProbe & (1 | 8 | 16 | 32)) != 0;  // (8, 16: the K-loop fed from L1 / L2 instead of its real operands)
 }
 
 static innr_status check_errflag(innr_ctx* c) {
     uint32_t e = 0;
     INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
     INNR_HIP_CHECK(ctx_sync(c));
-    if (const char* pb = getenv("INNR_I8H_PROBE"); pb && (atoi(pb) & 4)) {  // tools/i8h_probe.py: the one-limb int8 kernel's visit counters
+    if constexpr ((kI8hProbe & 4) != 0) {  // tools/i8h_probe.py: the one-limb int8 kernel's visit counters
         uint32_t h[18] = {0};
         INNR_HIP_CHECK(hipMemcpyAsync(h, c->flags.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -958,6 +1047,7 @@ innr_status innr_ctx_create(int device, innr_ctx** out) {
     innr_ctx* c = new (std::nothrow) innr_ctx();
     if (!c) return INNR_E_OOM;
     c->device = device;
+    tuning_from_env(&c->tune);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -986,7 +1076,7 @@ void innr_ctx_destroy(innr_ctx* c) {
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad, &c->q_hat,
                       &c->redo[0].q, &c->redo[0].idx, &c->redo[0].sc, &c->redo[0].map, &c->redo[0].qn,
-                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn};
+                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn, &c->kmargin};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)
@@ -1003,6 +1093,30 @@ innr_status innr_ctx_set_stream(innr_ctx* c, void* hip_stream) {
     c->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream (what torch uses unless told otherwise)
     c->own_stream = false;
     return INNR_OK;
+}
+
+innr_status innr_ctx_set_option(innr_ctx* c, const char* name, long value) {
+    if (!c || !name) return INNR_E_BAD_ARG;
+    INNR_ENTER(c);
+    for (const TuneName& n : kTuneNames)
+        if (!strcmp(n.name, name)) {
+            c->tune.*(n.field) = value;
+            return INNR_OK;
+        }
+    set_error("unknown option '%s'", name);
+    return INNR_E_BAD_ARG;
+}
+
+innr_status innr_ctx_get_option(innr_ctx* c, const char* name, long* value) {
+    if (!c || !name || !value) return INNR_E_BAD_ARG;
+    INNR_ENTER(c);
+    for (const TuneName& n : kTuneNames)
+        if (!strcmp(n.name, name)) {
+            *value = c->tune.*(n.field);
+            return INNR_OK;
+        }
+    set_error("unknown option '%s'", name);
+    return INNR_E_BAD_ARG;
 }
 
 innr_status innr_ctx_synchronize(innr_ctx* c) {
@@ -1130,6 +1244,7 @@ void innr_batch_free(innr_batch* b) {
     delete b;
 }
 
+#ifdef INNR_TEST_HOOKS  // libinnr_hip_testhooks.so only (make hooks): the product library exports no innrdbg_* symbol
 // Test hook: copy out the GEMM engine's last candidate selection (approximate composites) and its error-bound inputs.
 innr_status innrdbg_last_selection(innr_batch* b, size_t Q, size_t KP, uint64_t* sel, uint32_t* cnt, float* qnorm,
                                    float* info /* [0]=max_norm */) {
@@ -1171,6 +1286,8 @@ innr_status innrdbg_gemm_scores(innr_batch* b, int metric, const float* queries,
     INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
+
+#endif  // INNR_TEST_HOOKS
 
 // Second stage of the two-stage pipeline the reference describes (scalar.rs:366-368: batch_knn_u8 first pass, then an
 // exact re-rank on the full-precision vectors): exact scores of caller-given candidates in the reference's arithmetic
@@ -1524,13 +1641,13 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
         // a batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
         // everything else with room to spare (copies are kept for the batch's lifetime): the int8 one first (N*D bytes, the
         // faster kernel), else the bf16 one (N*D*2 bytes).
-        if (engine == INNR_KNN_MFMA && Q >= 128 && pick_kp(4 * kout + 64, 0) <= 256 && !getenv("INNR_NO_AUTO_BF16")) {
+        if (engine == INNR_KNN_MFMA && Q >= 128 && pick_kp(4 * kout + 64, 0) <= 256 && !b->ctx->tune.no_auto_bf16) {
             const bool cosm = metric == INNR_METRIC_COSINE;
             const int bfv = cosm ? kBfCos : (metric == INNR_METRIC_L2SQ ? kBfL2 : kBfDot);
             size_t free_b = 0, total_b = 0;
             const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
             const size_t slack = (size_t)8 << 30;
-            if (f32_i8_eligible(b, metric, Q, kout) && !getenv("INNR_NO_AUTO_I8") && !(cosm ? b->i8n_weak : b->i8_weak) &&
+            if (f32_i8_eligible(b, metric, Q, kout) && !b->ctx->tune.no_auto_i8 && !(cosm ? b->i8n_weak : b->i8_weak) &&
                 ((cosm ? b->Ai8n : b->Ai8) != nullptr || (have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
                 engine = INNR_KNN_MFMA_I8;
             else if ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
@@ -1587,7 +1704,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     if (engine == INNR_KNN_MFMA_I8 && i8h_probe_skips_visits()) {
-        set_error("INNR_I8H_PROBE bit 1 is set: the int8 filter kernel skipped its visits, this call was a timing run and its results are not valid");
+        set_error("this library is a timing build (-DINNR_I8H_PROBE): the int8 filter kernel skipped its visits, the call's results are not valid");
         return INNR_E_UNSUPPORTED;
     }
     return INNR_OK;
@@ -2045,19 +2162,22 @@ static innr_status knn_u8_mfma(innr_batch* b, const float* dQ, size_t Q, size_t 
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY((launch_gemm<kGemmU8, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, oq, nullptr, 0)));
-    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
-                        (uint32_t)Q));
     const float a255 = b->alpha / 255.0f;
     // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||, with ||c|| <= 255 sqrt(D)
     const float err_scale = 1.05f * fabsf(a255) * (2.0f * (float)b->D + 12.0f) * 5.9604645e-08f * 255.0f * sqrtf((float)b->D);
+    const float* kmargin = nullptr;
+    INNR_TRY(make_kmargin(c, 4, err_scale, qnorm, nullptr, nullptr, b->offset, qsum, Q, p.Qpad, &kmargin));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    INNR_TRY((launch_gemm<kGemmU8, 0>(b, p, Q, c->q_kmajor.as<float>(), nullptr, oq, nullptr, 0, nullptr, kmargin, (uint32_t)kout)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP,
+                        (uint32_t)Q));
 #define INNR_RESCORE_U8(RKV)                                                                                          \
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
                                                               (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
-                                                              d_out_score, fallback, nullptr, !getenv("INNR_RESCORE_ALL"))
+                                                              d_out_score, fallback, nullptr, !c->tune.rescore_all, nullptr, 0, \
+                                                              gthr_bounds(c, p.Qpad, p.KP))
     if (p.KP <= 64) INNR_RESCORE_U8(1);
     else if (p.KP <= 128) INNR_RESCORE_U8(2);
     else INNR_RESCORE_U8(4);
@@ -2082,10 +2202,7 @@ static uint32_t i8_nk(const innr_batch* b) { return (uint32_t)(round_up(b->D ? b
 // which int8 filter kernel: one limb on the matrix pipe + exact low-limb fix-up (default), or both limbs on the pipe
 // (INNR_I8_TWO_LIMB=1, and for candidate lists of 256: the one-limb kernel's visit path and a 1280-entry list compaction
 // do not fit the register file together -- tools/check_gemm_asm.py caught the operand ring being spilled)
-static bool i8_two_limb(size_t kout) {
-    const char* e = getenv("INNR_I8_TWO_LIMB");
-    return (e && atoi(e) != 0) || pick_kp(kout, 16) > 128;
-}
+static bool i8_two_limb(const innr_ctx* c, size_t kout) { return c->tune.i8_two_limb != 0 || pick_kp(kout, 16) > 128; }
 static uint32_t i8_shift(bool two) { return two ? 8u : (uint32_t)kI8hS; }
 
 static bool i8_eligible(const innr_batch* b, size_t Q) {
@@ -2119,7 +2236,7 @@ struct I8Plan {
 };
 static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0) {
     I8Plan p;
-    p.two = i8_two_limb(kout) || kp_override > 128;
+    p.two = i8_two_limb(b->ctx, kout) || kp_override > 128;
     const size_t bq = p.two ? (size_t)kI8BQ : (size_t)kI8hBQ;  // queries per block tile
     p.Qpad = round_up(Q, bq);
     p.nqt = (uint32_t)(p.Qpad / bq);
@@ -2143,21 +2260,18 @@ static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_ov
 
 template <int MODE>
 static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q, const float* qc, float* dump, size_t ld_dump,
-                                  const uint32_t* seed = nullptr, const char* corpus = nullptr) {
+                                  const uint32_t* seed = nullptr, const char* corpus = nullptr, const float* kmargin = nullptr,
+                                  uint32_t kk = 0) {
     if (!corpus) corpus = b->Ai8;
     innr_ctx* c = b->ctx;
-    const size_t nslot = p.Qpad * (size_t)kSlotMul * p.KP;
-    const size_t gbytes = (nslot + p.Qpad) * sizeof(uint32_t);
-    INNR_TRY(c->gthr.ensure(gbytes));
-    INNR_HIP_CHECK(hipMemsetAsync(c->gthr.p, 0, gbytes, c->stream));
-    uint32_t* gslots = c->gthr.as<uint32_t>();
-    if (seed) INNR_HIP_CHECK(hipMemcpyAsync(gslots + nslot, seed, p.Qpad * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    INNR_TRY(close_padding_queries(c, gslots + nslot, nreal_q, p.Qpad));
+    uint32_t* gslots = nullptr;
+    size_t nslot = 0;
+    if (!kmargin) kk = 0;
+    INNR_TRY(prep_gthr(c, p.Qpad, p.KP, seed, nreal_q, kmargin, &gslots, &nslot));
     const bool two = p.two;
 #define INNR_I8_ARGS                                                                                                      \
     corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
-        c->counts.as<uint32_t>(), p.KP, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump,                               \
-        (MODE == 0 && getenv("INNR_I8H_PROBE")) ? (size_t)atoi(getenv("INNR_I8H_PROBE")) : ld_dump
+        c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump
 #define INNR_I8_LAUNCH(RR)                                                                                                \
     do {                                                                                                                  \
         if (two) gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                  \
@@ -2212,29 +2326,33 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     // threshold seeding (cf. knn_mfma): the exact top-KP of a 2048-document prefix per query; their KP-th exact score
     // lowered by the query's error bound is a valid chip-wide bound from the first tile on
     const uint32_t* seed = nullptr;
-    const size_t kSeedN = seed_prefix_rows(true, Q);
-    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
-        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
-        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
-        INNR_TRY(knn_u8_exact_range(b, dQ, b->D, qsum, 0, Q, p.KP, c->seed_idx.as<uint64_t>(), c->seed_score.as<float>(), kSeedN));
-        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
+    const size_t kSeedN = seed_prefix_rows(c, true, Q);
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
+        const uint32_t kseed = c->tune.no_k_rule ? p.KP : (uint32_t)kout;  // (see knn_mfma)
+        INNR_TRY(c->seed_idx.ensure(Q * kseed * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * kseed * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_u8_exact_range(b, dQ, b->D, qsum, 0, Q, kseed, c->seed_idx.as<uint64_t>(), c->seed_score.as<float>(), kSeedN));
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * kseed);
         seed_thresholds_u8_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(
-            c->seed_score.as<float>(), (uint32_t)Q, p.KP, err_scale, qnorm, qsum, b->offset, qc + 3 * p.Qpad, sd, (uint32_t)p.Qpad);
+            c->seed_score.as<float>(), (uint32_t)Q, kseed, err_scale, qnorm, qsum, b->offset, qc + 3 * p.Qpad, sd, (uint32_t)p.Qpad,
+            kseed - 1);
         INNR_HIP_CHECK(hipGetLastError());
         seed = sd;
     }
     INNR_TRY(c->lists.ensure((size_t)p.nslices * p.Qpad * p.cap * sizeof(uint64_t)));
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
+    const float* kmargin = nullptr;
+    INNR_TRY(make_kmargin(c, 4, err_scale, qnorm, nullptr, qc + 3 * p.Qpad, b->offset, qsum, Q, p.Qpad, &kmargin));
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed));
+    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, nullptr, kmargin, (uint32_t)kout));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
 #define INNR_RESCORE_U8(RKV)                                                                                          \
     rescore_u8_kernel<RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->C8, b->ldN, (uint32_t)b->D, dQ, qsum, qnorm, a255, b->offset, \
                                                               c->sel.as<uint64_t>(), c->sel_cnt.as<uint32_t>(), p.KP,   \
                                                               (uint32_t)kout, err_scale, b->index_base, d_out_idx,      \
-                                                              d_out_score, fallback, qc + 3 * p.Qpad, !getenv("INNR_RESCORE_ALL"),  \
-                                                              reinterpret_cast<const uint4*>(b->Ai8), b->ai8_nk)
+                                                              d_out_score, fallback, qc + 3 * p.Qpad, !c->tune.rescore_all,  \
+                                                              reinterpret_cast<const uint4*>(b->Ai8), b->ai8_nk, gthr_bounds(c, p.Qpad, p.KP))
     if (p.KP <= 64) INNR_RESCORE_U8(1);
     else if (p.KP <= 128) INNR_RESCORE_U8(2);
     else INNR_RESCORE_U8(4);
@@ -2253,6 +2371,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     return redo_batch_u8(b, dQ, qsum, redo, kout, d_out_idx, d_out_score);
 }
 
+#ifdef INNR_TEST_HOOKS
 // Test hook (not part of the ABI): dense approximate score matrix of the int8 engine, out[q*N + i] = A_q V(q, i) + B_q, and
 // the per-query constants qc[4][Qpad] -- to check the int8 MFMA operand layout and the limb arithmetic exactly.
 extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, size_t Q, size_t D, float* out, float* qc_out,
@@ -2279,6 +2398,7 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
     INNR_HIP_CHECK(ctx_sync(c));
     return INNR_OK;
 }
+#endif  // INNR_TEST_HOOKS
 
 // ---- the int8 filter in front of an F32 corpus (INNR_KNN_MFMA_I8 on an f32 batch; dot and cosine) ------------------------------
 // The corpus is scalar-quantised once with a single (offset, alpha) -- the reference's own quantize_u8 with the corpus' range,
@@ -2382,15 +2502,16 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
     const uint32_t* seed = nullptr;
-    const size_t kSeedN = seed_prefix_rows(true, Q);
-    if (b->N >= 32 * kSeedN && p.KP <= 128 && !getenv("INNR_GEMM_NO_SEED")) {
-        INNR_TRY(c->seed_idx.ensure(Q * p.KP * sizeof(uint64_t)));
-        INNR_TRY(c->seed_score.ensure(Q * p.KP * sizeof(float) + p.Qpad * sizeof(uint32_t)));
-        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, p.KP, c->seed_idx.as<uint64_t>(),
+    const size_t kSeedN = seed_prefix_rows(c, true, Q);
+    if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
+        const uint32_t kseed = c->tune.no_k_rule ? p.KP : (uint32_t)kout;  // (see knn_mfma)
+        INNR_TRY(c->seed_idx.ensure(Q * kseed * sizeof(uint64_t)));
+        INNR_TRY(c->seed_score.ensure(Q * kseed * sizeof(float) + p.Qpad * sizeof(uint32_t)));
+        INNR_TRY(knn_exact_range(b, metric, dQ, b->D, c->q_norm.as<float>(), 0, Q, kseed, c->seed_idx.as<uint64_t>(),
                                  c->seed_score.as<float>(), ScanExt(), kSeedN));
-        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * p.KP);
-        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->seed_score.as<float>(), (uint32_t)Q, p.KP, eq, sd,
-                                                                                       (uint32_t)p.Qpad);
+        uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * kseed);
+        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->seed_score.as<float>(), (uint32_t)Q, kseed, eq, sd,
+                                                                                       (uint32_t)p.Qpad, kseed - 1);
         INNR_HIP_CHECK(hipGetLastError());
         seed = sd;
     }
@@ -2398,8 +2519,10 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     INNR_TRY(c->counts.ensure((size_t)p.nslices * p.Qpad * sizeof(uint32_t)));
     INNR_TRY(c->sel.ensure(Q * p.KP * sizeof(uint64_t)));
     INNR_TRY(c->sel_cnt.ensure(Q * sizeof(uint32_t)));
+    const float* kmargin = nullptr;
+    INNR_TRY(make_kmargin(c, 3, 0.0f, nullptr, nullptr, eq, 0.0f, nullptr, Q, p.Qpad, &kmargin));
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, cos ? b->Ai8n : b->Ai8));
+    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, cos ? b->Ai8n : b->Ai8, kmargin, (uint32_t)kout));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
 #define INNR_RESCORE_EQ(METV, RKV)                                                                                   \
@@ -2407,7 +2530,7 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
                                                                  c->q_norm.as<float>(), nullptr, c->sel.as<uint64_t>(), \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout, 0.0f, \
                                                                  b->index_base, d_out_idx, d_out_score, fallback, eq,   \
-                                                                 !getenv("INNR_RESCORE_ALL"))
+                                                                 !c->tune.rescore_all, gthr_bounds(c, p.Qpad, p.KP))
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
         if (rk == 1) INNR_RESCORE_EQ(1, 1); else if (rk == 2) INNR_RESCORE_EQ(1, 2); else INNR_RESCORE_EQ(1, 4);
@@ -2454,7 +2577,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) {
         engine = innr_batch_auto_engine(b, Q);
-        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !getenv("INNR_U8_NO_I8")) {
+        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !c->tune.u8_no_i8) {
             // the int8 filter's smallest tile is 512 queries (46 ms at 50M x 768 whatever the batch size); the exact engine's
             // 8-query passes cost 17.7 ms each there: two passes still win (profiles/r02_u8_exact_scan_50Mx768.txt)
             engine = Q <= 16 ? INNR_KNN_EXACT : INNR_KNN_MFMA_I8;
@@ -2487,7 +2610,7 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     if (engine == INNR_KNN_MFMA_I8 && i8h_probe_skips_visits()) {
-        set_error("INNR_I8H_PROBE bit 1 is set: the int8 filter kernel skipped its visits, this call was a timing run and its results are not valid");
+        set_error("this library is a timing build (-DINNR_I8H_PROBE): the int8 filter kernel skipped its visits, the call's results are not valid");
         return INNR_E_UNSUPPORTED;
     }
     return INNR_OK;
@@ -2824,7 +2947,7 @@ static innr_status maxsim_approx(innr_docs* d, int cosine, const float* const* q
     const size_t qb_stride = dim * 32;  // floats per packed query: [dim/8][64][4]
     const size_t lds = (size_t)nqr * qb_stride * sizeof(float);
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((d->ndocs + 3) / 4, (size_t)c->num_cus * 8));
-    const bool tiled = dim % 32 == 0 && dim <= 128 && !getenv("INNR_MAXSIM_GENERIC");
+    const bool tiled = dim % 32 == 0 && dim <= 128 && !d->ctx->tune.maxsim_generic;
     uint32_t* nq_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(c->misc.p) + 16384);  // token counts, 4 per pass
     for (size_t p0 = 0; p0 < Tq_pad; p0 += kMsQ) {
         uint32_t nq_host[4] = {0, 0, 0, 0};
@@ -3041,7 +3164,7 @@ innr_status innr_maxsim_topk_multi(innr_docs* d, int cosine, const float* qtoks,
         if (!(d->max_norm - d->max_norm == 0.0f)) use_mfma = false;  // a non-finite token: nothing can be proven
     }
     // groups of 4 / 2 queries share a corpus pass when the tile-unrolled kernel applies and every query fits one pass
-    const bool groupable = use_mfma && dim % 32 == 0 && dim <= 128 && tq_max <= (size_t)kMsQ && !getenv("INNR_MAXSIM_GENERIC");
+    const bool groupable = use_mfma && dim % 32 == 0 && dim <= 128 && tq_max <= (size_t)kMsQ && !d->ctx->tune.maxsim_generic;
     std::vector<uint8_t> done(Q, 0);
     uint32_t KP = 0, nfallback = 0;
     float scan_ms = 0.0f;

@@ -148,8 +148,10 @@ template <int KIND, int R, int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void gemm_filter_kernel(
     const void* __restrict__ Vraw, size_t ldN, uint32_t N, uint32_t Dpad, const float* __restrict__ Qt, size_t Qpad,
     uint32_t nqt, uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ invn, const float* __restrict__ invq, float scale,
-    uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t* __restrict__ errflag,
-    uint32_t* gslots /*[Qpad][kSlotMul * KP]*/, uint32_t* gthr /*[Qpad]*/, float* __restrict__ dump, size_t ld_dump) {
+    uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag,
+    uint32_t* gslots /*[Qpad][kSlotMul * KP]*/, uint32_t* gthr /*[Qpad] bounds, then [Qpad] k-rule margins (float)*/,
+    float* __restrict__ dump, size_t ld_dump) {
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);  // 2E per query: the k rule of topk_dev.h
     constexpr bool COS = KIND == kGemmCos;
     constexpr bool U8 = KIND == kGemmU8;
     constexpr bool L2K = KIND == kGemmL2;
@@ -466,11 +468,13 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
                                                      float err_scale, uint64_t index_base,
                                                      uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                      uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr,
-                                                     bool early = false) {
+                                                     bool early = false, const uint32_t* __restrict__ gthr = nullptr) {
     constexpr bool COS = MET == 1, L2 = MET == 2;
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
+    // the query's final chip-wide bound (topk_dev.h; 0 = none): every site the filter rejected had an approximate score below it
+    const uint32_t G = gthr ? gthr[q] : 0u;
     const float* qv = Qm + (size_t)q * D;
     const float qn = L2 ? 0.0f : qnorm[q];
     uint64_t e[RK];
@@ -530,10 +534,20 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
         }
         // margin proof (one lane holds the k-th best exact score)
         bool bad = false;
-        if (have_kth && (!last || cnt == KP)) {  // last round with cnt < KP: every corpus vector is a candidate, nothing to prove
+        // T: no candidate that has not been re-scored, and no vector outside the lists, has a better approximate score -- outsiders
+        // were either dropped from a full list (<= the KP-th approximate score) or rejected by a threshold (< the final bound G).
+        // Last round with cnt < KP and no bound: every corpus vector is a candidate, nothing to prove.
+        uint32_t tp = G;
+        bool prove = G != 0u;
+        if (!last || cnt == KP) {
+            const uint32_t lp = cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]);
+            tp = (!prove || lp > tp) ? lp : tp;
+            prove = true;
+        }
+        if (last && G != 0u && cnt < kout) bad = true;  // (cannot happen: at least k sites clear a bound of either rule)
+        if (have_kth && prove) {
             const float exact_k = pref_score(kth_bits, L2);
-            // T: no candidate that has not been re-scored, and no vector outside the lists, has a better approximate score
-            const float T = ord_f32(cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]));
+            const float T = ord_f32(tp);
             if (L2) {
                 // outsiders: approx <= T, i.e. their approximate distance C - approx >= C - T, exact >= C - T - E
                 const float Cq = qaux[q];
@@ -626,19 +640,22 @@ __global__ __launch_bounds__(256) void rerank_scores_kernel(const float* __restr
 // the approximation error bound E (so that all KP of them are certain to clear it with their APPROXIMATE scores), is a
 // valid chip-wide bound from the first tile on. kind: 0 dot (E = err_scale*|q|), 1 cosine (E = err_scale),
 // 2 squared L2 in the epilogue's score space s = C - dist (E = err_scale*C). seed[j] = 0 ("no bound") when not finite.
+// pos: which of the prefix's exact scores seeds the bound -- KP - 1 (the KP rule of topk_dev.h: all KP of them clear it with their
+// approximate scores) or k - 1 (the k rule: the k-th best exact score of the WHOLE corpus is at least the prefix's, so a vector
+// whose approximate score is below it by more than E is not in the top k); one key lower, so that the re-score's proof is strict.
 __global__ void seed_thresholds_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
                                        int kind, float err_scale, const float* __restrict__ qnorm, const float* __restrict__ Cj,
-                                       uint32_t* __restrict__ seed /*[Qpad]*/, uint32_t Qpad) {
+                                       uint32_t* __restrict__ seed /*[Qpad]*/, uint32_t Qpad, uint32_t pos) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Qpad) return;
     uint32_t o = 0;
     if (j < Q) {
-        const float x = kth_scores[(size_t)j * KP + KP - 1];
+        const float x = kth_scores[(size_t)j * KP + pos];
         float t;
         if (kind == 2) t = (Cj[j] - x) - err_scale * Cj[j] * 1.0001f;
         else if (kind == 1) t = x - err_scale * 1.0001f;
         else t = x - err_scale * qnorm[j] * 1.0001f;
-        if (t - t == 0.0f) o = f32_ord(t);
+        if (t - t == 0.0f) o = f32_ord(t) - 1u;
     }
     seed[j] = o;
 }

@@ -127,8 +127,9 @@ struct alignas(16) GemmBf16Lds {
 template <int R, int MODE>
 __global__ __launch_bounds__(64 * kBfWaves, 1) void gemm_bf16_filter_kernel(
     const char* __restrict__ Ab, const char* __restrict__ Bb, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
-    uint32_t qtg, uint32_t tiles_per_slice, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP,
+    uint32_t qtg, uint32_t tiles_per_slice, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk,
     uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);  // 2E per query: the k rule of topk_dev.h
     constexpr bool COS = false, U8 = false, L2K = false;  // kind flags of the shared epilogue: plain dot scores
     const float* const invn = nullptr;
     const float* const invq = nullptr;

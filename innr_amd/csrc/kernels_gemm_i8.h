@@ -164,13 +164,13 @@ __global__ void f32i8_finish_bound_kernel(float* __restrict__ qc, uint32_t Qpad,
 }
 
 __global__ void seed_thresholds_eq_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
-                                          const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad) {
+                                          const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad, uint32_t pos) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Qpad) return;
     uint32_t o = 0;
     if (j < Q) {
-        const float t = kth_scores[(size_t)j * KP + KP - 1] - eq[j] * 1.0001f - 1e-30f;
-        if (t - t == 0.0f) o = f32_ord(t);
+        const float t = kth_scores[(size_t)j * KP + pos] - eq[j] * 1.0001f - 1e-30f;  // pos: see seed_thresholds_kernel
+        if (t - t == 0.0f) o = f32_ord(t) - 1u;
     }
     seed[j] = o;
 }
@@ -256,15 +256,16 @@ __global__ __launch_bounds__(64) void pack_queries_i8_kernel(const float* __rest
 // at least KP documents have an APPROXIMATE score above it, so it is a valid chip-wide bound. 0 = "no bound".
 __global__ void seed_thresholds_u8_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
                                           float err_scale, const float* __restrict__ qnorm, const float* __restrict__ qsum,
-                                          float offset, const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad) {
+                                          float offset, const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad,
+                                          uint32_t pos) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Qpad) return;
     uint32_t o = 0;
     if (j < Q) {
-        const float x = kth_scores[(size_t)j * KP + KP - 1];
+        const float x = kth_scores[(size_t)j * KP + pos];  // pos: see seed_thresholds_kernel
         const float E = err_scale * qnorm[j] + 4.8e-7f * fabsf(offset * qsum[j]) + eq[j];
         const float t = x - E * 1.0001f - 1e-30f;
-        if (t - t == 0.0f) o = f32_ord(t);
+        if (t - t == 0.0f) o = f32_ord(t) - 1u;
     }
     seed[j] = o;
 }
@@ -282,7 +283,8 @@ template <int R, int MODE>
 __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
     uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ qc, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
-    uint32_t KP, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);  // 2E per query: the k rule of topk_dev.h
     constexpr int kEpiTgWait = 5 * (kI8Stages - 3) + 4 + 5;
     __shared__ GemmI8Lds s;
     constexpr uint32_t cap = 64 * R;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
                     const float thr_f = ord_f32(thr);
                     if (thr != 0u) {
                         const float x = (thr_f - Bj) * invAj;
-                        if (x >= 2.0e9f || thr == 0xFFFFFFFFu) Tint = INT32_MAX;  // (all ones: a padding query, closed by the host)
+                        if (x >= 2147483520.0f || thr == 0xFFFFFFFFu) Tint = INT32_MAX;  // beyond every legal V (|V| < 2^31; all ones: a padding query, closed by the host)
                         else if (x > -2.0e9f) Tint = (int32_t)__builtin_floorf(x) - 2 - (int32_t)(fabsf(x) * 4.8e-7f);
                         // x <= -2e9 or NaN: everything passes
                     }
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
                             const int L = __builtin_ctzll(m);
                             m &= m - 1;
                             const size_t qg = q0 + 32 * wu + L;  // wave-uniform
-                            gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);
+                            gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane, kk, kmargin[qg]);
                         }
                         __builtin_amdgcn_wave_barrier();
                         // compact the lists of this wave's 32 queries that are running out of room
@@ -551,6 +553,15 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 #ifndef INNR_I8H_S
 #define INNR_I8H_S 6
 #endif
+// Timing probes of the one-limb kernel are COMPILE-TIME switches (builds with -DINNR_I8H_PROBE=<bits>, tools/i8h_probe.py;
+// the product library is built without them: no probe branch exists in its K-loop). Bits -- 1: the epilogue never visits (what the
+// K-loop and the fast reject cost); 8 / 16: the query fragments of every K-step come from step 0 (L1) / every DMA re-reads the
+// slice's first stage (L2); 32: no epilogue at all; 4: count visiting wave epilogues / survivors / bound re-derivations and the
+// cycles they take into errflag[8..17]. Builds with bits 1, 8, 16 or 32 give wrong answers and their calls fail after filling the stats.
+#ifndef INNR_I8H_PROBE
+#define INNR_I8H_PROBE 0
+#endif
+constexpr uint32_t kI8hProbe = INNR_I8H_PROBE;
 constexpr int kI8hBQ = 512, kI8hS = INNR_I8H_S;
 
 constexpr int kI8hSurvCap = 128;  // survivors a wave queues before it finishes them (at least one round: 64)
@@ -584,7 +595,8 @@ template <int R, int MODE>
 __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
     uint32_t qtg, uint32_t tiles_per_slice, const float* __restrict__ qc, uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
-    uint32_t KP, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr, float* __restrict__ dump, size_t ld_dump) {
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);  // 2E per query: the k rule of topk_dev.h
     constexpr int kEpiTgWait = 5 * (kI8Stages - 3) + 4 + 5;
     constexpr int S = kI8hS;
     __shared__ GemmI8hLds s;
@@ -630,15 +642,13 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     const uint32_t va = (uint32_t)lane * 16u;
     const uint32_t lds0 = lds_addr_uniform(&s.A[0]) + (uint32_t)wu * 1024u;
     // Bq[ks][kg][limb][Qpad][16]: depth m of a lane half h is kg = 2 m + h; only limb 0 feeds the matrix pipe
-    // (INNR_I8H_PROBE bit 8, timing only: every K-step reads the query fragments of step 0 -- they stay in the CU's L1)
-    const size_t b_step = (MODE == 0 && (ld_dump & 8)) ? 0 : (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_ct = 32 * 16;
+    const size_t b_step = (MODE == 0 && (kI8hProbe & 8)) ? 0 : (size_t)8 * Qpad * 16, b_depth = (size_t)4 * Qpad * 16, b_ct = 32 * 16;
     const char* sb = Bq + (q0 + (size_t)wu * 64) * 16;
     const uint32_t vb = ((uint32_t)half * 2u * (uint32_t)Qpad + (uint32_t)C) * 16u;
     uint32_t a_issued = 0, b_ks = 0;
     const uint32_t last = total ? total - 1 : 0;
     auto issue_a = [&]() {
-        // (INNR_I8H_PROBE bit 16, timing only: every DMA re-reads the slice's first stage -- the corpus stream comes from L2)
-        const uint32_t st = (MODE == 0 && (ld_dump & 16)) ? 0u : (a_issued < total ? a_issued : last);
+        const uint32_t st = (MODE == 0 && (kI8hProbe & 16)) ? 0u : (a_issued < total ? a_issued : last);
         glds16(uniform_ptr(sa + (size_t)st * kI8StageBytes), va, lds0 + (a_issued % kI8Stages) * kI8StageBytes);
         ++a_issued;
     };
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
         for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
     }
     uint32_t tile = t0, ks = 0;
-    // INNR_I8H_PROBE bit 4 (tools/i8h_probe.py): per wave, flushed once at the end -- per-event atomics on one address slowed the kernel 5x
+    // probe bit 4 (tools/i8h_probe.py): per wave, flushed once at the end -- per-event atomics on one address slowed the kernel 5x
     uint32_t pc_nvis = 0, pc_nsurv = 0, pc_npub = 0;
     unsigned long long pc_visit = 0, pc_surv = 0, pc_tail = 0;  // cycles inside visits / inside the survivors' loops / publish + compaction
     for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
@@ -735,7 +745,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                 dump[q * ld_dump + i] = __builtin_fmaf(Aj[ct], (float)V, Bj[ct]);
                             }
                     }
-                } else if (ld_dump & 32) {  // INNR_I8H_PROBE bit 32, timing only: no epilogue at all (the bare K-loop)
+                } else if (kI8hProbe & 32) {  // timing only: no epilogue at all (the bare K-loop)
                     use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
                 } else {
                     use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         Thi[ct] = INT32_MIN;
                         if (thr[ct] != 0u) {
                             const float x = (thr_f[ct] - Bj[ct]) * invAj[ct];
-                            if (x >= 2.0e9f || thr[ct] == 0xFFFFFFFFu) {
+                            if (x >= 2147483520.0f || thr[ct] == 0xFFFFFFFFu) {  // beyond every legal V (|V| < 2^31), or a padding query
                                 Tint[ct] = INT32_MAX;
                                 Thi[ct] = INT32_MAX;
                             } else if (x > -2.0e9f) {
@@ -783,10 +793,8 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         const int32_t b23 = gbest[ct][2] > gbest[ct][3] ? gbest[ct][2] : gbest[ct][3];
                         hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
                     }
-                    // (MODE 0 has no use for ld_dump: INNR_I8H_PROBE passes probe bits there -- 1: never visit, 8: query fragments from L1, 16: corpus stages from L2, 32: no epilogue (timing only, wrong
-                    //  answers), 4: count visits / survivors / bound re-derivations and the cycles they take into errflag[8..17]; tools/i8h_probe.py)
-                    const bool probe = (ld_dump & 4) != 0;
-                    if (__any(hit[0] || hit[1]) && !(ld_dump & 1)) {
+                    constexpr bool probe = (kI8hProbe & 4) != 0;
+                    if (__any(hit[0] || hit[1]) && !(kI8hProbe & 1)) {
                         const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
                         pc_nvis += probe ? 1u : 0u;
                         // A visit borrows the K-loop's operand ring: once everything the wave has in flight has landed (the wait
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                 const int L = __builtin_ctzll(m);
                                 m &= m - 1;
                                 const size_t qg = q0 + 64 * wu + 32 * ct + L;  // wave-uniform
-                                gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane);
+                                gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane, kk, kmargin[qg]);
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -979,7 +987,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     }
     wait_all();
     __syncthreads();
-    if (MODE == 0 && (ld_dump & 4) && lane == 0) {
+    if (MODE == 0 && (kI8hProbe & 4) && lane == 0) {
         atomicAdd(errflag + 8, pc_nvis);
         atomicAdd(errflag + 9, pc_nsurv);
         atomicAdd(errflag + 10, pc_npub);

@@ -292,10 +292,12 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
                                                         uint32_t KP, uint32_t kout, float err_scale, uint64_t index_base,
                                                         uint64_t* __restrict__ out_idx, float* __restrict__ out_score,
                                                         uint32_t* __restrict__ fallback, const float* __restrict__ eq = nullptr,
-                                                        bool early = false, const uint4* __restrict__ Ai8 = nullptr, uint32_t nk = 0) {
+                                                        bool early = false, const uint4* __restrict__ Ai8 = nullptr, uint32_t nk = 0,
+                                                        const uint32_t* __restrict__ gthr = nullptr) {
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t cnt = sel_cnt[q];
+    const uint32_t G = gthr ? gthr[q] : 0u;  // the query's final chip-wide bound (see rescore_kernel)
     const float* qv = Qm + (size_t)q * D;
     const float qs = qsum[q];
     uint64_t e[RK];
@@ -358,9 +360,17 @@ __global__ __launch_bounds__(64) void rescore_u8_kernel(const uint8_t* __restric
             }
         }
         bool bad = false;
-        if (have_kth && (!last || cnt == KP)) {
+        uint32_t tp = G;
+        bool prove = G != 0u;
+        if (!last || cnt == KP) {
+            const uint32_t lp = cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]);
+            tp = (!prove || lp > tp) ? lp : tp;
+            prove = true;
+        }
+        if (last && G != 0u && cnt < kout) bad = true;
+        if (have_kth && prove) {
             const float exact_k = ord_f32(kth_bits);
-            const float T = ord_f32(cand_pref(sel[(size_t)q * KP + (last ? KP - 1 : done)]));
+            const float T = ord_f32(tp);
             // |approx - exact| <= a255 * (2D+12) u * ||q|| * max||c||  +  8u * |offset * sum(q)|
             // eq[q] (int8 filter engine): the query's own share of the bound (its 16-bit quantisation), +inf = unprovable
             const float E = err_scale * qnorm[q] + 4.8e-7f * fabsf(ex::mul(offset, qs)) + (eq ? eq[q] : 0.0f);

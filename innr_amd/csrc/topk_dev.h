@@ -81,21 +81,53 @@ constexpr uint32_t kSlotMul = INNR_SLOT_MUL;
 #endif
 constexpr uint32_t kPubEvery = INNR_PUB_EVERY;
 
-// KP-th largest of the S = kSlotMul*KP slot values of one query (wave-uniform arguments), by bisection on the 32 key
-// bits with ballot counts: t = max{x : #(slots >= x) >= KP}; 0 while fewer than KP slots are filled.
+// The chip-wide bound of one query, re-derived from its S = kSlotMul*KP slot values (wave-uniform arguments). Two rules, both
+// certificates, the better one wins:
+//   KP rule  t_KP = the KP-th largest slot value: at least KP vectors score >= t_KP, so nothing below it is in the top KP.
+//   k rule   t_k = the kk-th largest slot value (kk = the k the caller asked for): at least k vectors have an APPROXIMATE score
+//            >= t_k, hence an exact score >= t_k - E (E = the query's bound on |approx - exact|), hence the k-th best EXACT
+//            score s_k >= t_k - E, and a vector whose approximate score is below t_k - 2E has an exact score below s_k: it
+//            is not in the top k. The caller passes kmargin = 2E (+ rounding room; +inf switches the rule off) and the bound
+//            is set one key below t_k - kmargin, so that the re-score's proof "k-th exact > bound + E" is strict.
+//   With the KP rule alone the bound sits near global rank 1.4 KP whatever the filter's precision; the k rule puts it where
+//   the proof needs it: at C2 (k = 10, int8 filter, 2E = 3.1 against a gap of 5.0 between the 10th and the 128th score) near
+//   rank 50 instead of 180, i.e. a third of the survivors per tile -- and the lists' length KP becomes a capacity, not the
+//   quantity that sets the threshold. The re-score (rescore_kernel, rescore_u8_kernel) proves against the FINAL bound of the
+//   query (gthr only grows, so every threshold a site was rejected with is <= it).
+// Bisection on the 32 key bits with ballot counts: select(n) = max{x : #(slots >= x) >= n}; 0 while fewer than n are filled.
 template <int NR>  // NR = S / 64 slot values per lane
-__device__ __forceinline__ void gthr_publish_select(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane) {
+__device__ __forceinline__ void gthr_publish_select(const uint32_t* slots, uint32_t* gthr_q, uint32_t KP, int lane,
+                                                    uint32_t kk = 0u, float kmargin = __builtin_inff()) {
     uint32_t v[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) v[r] = __hip_atomic_load(slots + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t t = 0;
-#pragma unroll 1
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = t | (1u << bit);
+    auto count_ge = [&](uint32_t x) -> uint32_t {
         uint32_t cnt = 0;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) cnt += (uint32_t)__popcll(__ballot(v[r] >= cand));
-        if (cnt >= KP) t = cand;
+        for (int r = 0; r < NR; ++r) cnt += (uint32_t)__popcll(__ballot(v[r] >= x));
+        return cnt;
+    };
+    auto select = [&](uint32_t n) -> uint32_t {
+        uint32_t t = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = t | (1u << bit);
+            if (count_ge(cand) >= n) t = cand;
+        }
+        return t;
+    };
+    uint32_t g = 0;
+    if (kk) {
+        const uint32_t tk = select(kk);
+        if (tk) {
+            const float x = ord_f32(tk) - kmargin;
+            if (x - x == 0.0f) g = f32_ord(x) - 1u;  // finite x: its key is >= 0x00800000
+        }
+    }
+    uint32_t t = g;
+    if (!g || count_ge(g) >= KP) {  // the KP rule may be the stronger one (always, while the k rule has nothing to say)
+        const uint32_t tkp = select(KP);
+        t = tkp > t ? tkp : t;
     }
     if (lane == 0 && t) (void)__hip_atomic_fetch_max(gthr_q, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -7,7 +7,7 @@
 #![allow(clippy::missing_safety_doc)]
 
 pub mod ffi {
-    use std::os::raw::{c_char, c_int, c_void};
+    use std::os::raw::{c_char, c_int, c_long, c_void};
     #[repr(C)]
     pub struct InnrCtx { _p: [u8; 0] }
     #[repr(C)]
@@ -35,13 +35,20 @@ pub mod ffi {
     pub const INNR_KNN_AUTO: c_int = 0;
     pub const INNR_KNN_EXACT: c_int = 1;
     pub const INNR_KNN_MFMA: c_int = 2;
-    pub const INNR_KNN_MFMA_BF16: c_int = 3; // bf16 filter + exact f32 re-score and proof: same results (dot, k <= 48)
+    pub const INNR_KNN_MFMA_BF16: c_int = 3; // bf16 filter + exact f32 re-score and proof: same results
+    pub const INNR_KNN_MFMA_I8: c_int = 4; // int8 filter (code corpora; f32 corpora through a scalar-quantised copy): same results
+    pub const INNR_E_BAD_ARG: c_int = -2;
+    pub const INNR_E_OOM: c_int = -3;
+    pub const INNR_E_HIP: c_int = -4;
+    pub const INNR_E_UNSUPPORTED: c_int = -6;
     extern "C" {
         // ---- generated from include/innr_hip.h by tools/gen_rust_ffi.py: begin
         pub fn innr_ctx_create(device: c_int, out: *mut *mut InnrCtx) -> c_int;
         pub fn innr_ctx_destroy(ctx: *mut InnrCtx);
         pub fn innr_ctx_set_stream(ctx: *mut InnrCtx, hip_stream: *mut c_void) -> c_int;
         pub fn innr_ctx_synchronize(ctx: *mut InnrCtx) -> c_int;
+        pub fn innr_ctx_set_option(ctx: *mut InnrCtx, name: *const c_char, value: c_long) -> c_int;
+        pub fn innr_ctx_get_option(ctx: *mut InnrCtx, name: *const c_char, value: *mut c_long) -> c_int;
         pub fn innr_last_error() -> *const c_char;
         pub fn innr_version() -> *const c_char;
         pub fn innr_batch_upload_colmajor(ctx: *mut InnrCtx, data: *const f32, n: usize, d: usize, out: *mut *mut InnrBatch) -> c_int;

@@ -16,6 +16,38 @@ def pytest_configure(config):
     oracle.lib()
 
 
+def hooks_lib():
+    """innr_amd/lib/libinnr_hip_testhooks.so: the product sources built with -DINNR_TEST_HOOKS (make hooks) -- the innrdbg_*
+    layout hooks live only there. It takes handles made by the product library (same structs, same HIP runtime)."""
+    import ctypes as C
+    global _HOOKS
+    if _HOOKS is None:
+        path = os.path.join(ROOT, "innr_amd", "lib", "libinnr_hip_testhooks.so")
+        if not os.path.exists(path):
+            pytest.skip("libinnr_hip_testhooks.so not built (make -C innr_amd/csrc hooks)")
+        _HOOKS = C.CDLL(path)
+    return _HOOKS
+
+
+_HOOKS = None
+
+
+@pytest.fixture
+def ctx_option():
+    """set a tuning option of the default context for one test (innr_ctx_set_option), restored afterwards"""
+    from innr_amd import _lib
+    ctx = _lib.default_context()
+    saved = []
+
+    def _set(name, value):
+        saved.append((name, ctx.get_option(name)))
+        ctx.set_option(name, value)
+
+    yield _set
+    for name, old in reversed(saved):
+        ctx.set_option(name, old)
+
+
 def _have_gpu() -> bool:
     # /dev/kfd is what the HIP runtime needs; avoids initialising anything in CPU-only runs.
     return os.path.exists("/dev/kfd")

@@ -13,7 +13,8 @@ st = KnnStats()
 idx, sc = B.batch_knn_dot_multi(qs, vb, k, engine=KNN_MFMA, stats=st)
 print("fallback", st.queries_fallback, "kept", st.candidates_kept, "gemm_ms", st.gemm_ms)
 KP = st.candidates_kept
-L = _lib.load()
+import ctypes as _C, os as _os
+L = _C.CDLL(_os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "innr_amd", "lib", "libinnr_hip_testhooks.so"))  # make -C innr_amd/csrc hooks
 sel = np.zeros((nq, KP), np.uint64); cnt = np.zeros(nq, np.uint32); qn = np.zeros(nq, np.float32); info = np.zeros(4, np.float32)
 fn = L.innrdbg_last_selection; fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

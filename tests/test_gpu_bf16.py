@@ -49,13 +49,10 @@ def test_bf16_cosine_zero_norms_and_auto(B, innr):
     B.batch_knn_cosine_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
     assert st.engine == innr.KNN_MFMA_I8  # there is room for the int8 filter copy: AUTO takes the fastest filter that applies
     _check_knn(B, innr, "cos", vb, data, qs, 10, innr.KNN_AUTO)
-    import os
-    os.environ["INNR_NO_AUTO_I8"] = "1"
-    try:
+    from innr_amd import _lib
+    with _lib.default_context().option("no_auto_i8", 1):
         B.batch_knn_cosine_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
         assert st.engine == innr.KNN_MFMA_BF16  # ... the bf16 one when the int8 one is ruled out (its copy exists already)
-    finally:
-        del os.environ["INNR_NO_AUTO_I8"]
     _check_knn(B, innr, "dot", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
     assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter (there is no int8 one for it)

@@ -29,8 +29,8 @@ def innr():
 
 def _dense_scores(vb, metric, queries):
     from innr_amd import _lib
-    L = _lib.load()
-    fn = L.innrdbg_gemm_scores  # test hook, deliberately outside include/innr_hip.h
+    from conftest import hooks_lib
+    fn = hooks_lib().innrdbg_gemm_scores  # test hook: outside include/innr_hip.h and outside the product library
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     q = np.ascontiguousarray(queries, np.float32)
@@ -364,13 +364,14 @@ def test_config5_cosine_4096_queries_two_logical_shards(B, innr):
 
 
 @pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
-def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves, monkeypatch):
+def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves):
     # plan_gemm picks 8-wave (512-query) tiles for dot with many queries, 4-wave tiles for cosine / L2, 1- and 2-wave
-    # (64- / 128-query) tiles for small batches; INNR_GEMM_WAVES forces any of them, so every (kind, block shape)
+    # (64- / 128-query) tiles for small batches; the context option gemm_waves forces any of them, so every (kind, block shape)
     # instantiation stays under test -- here with 600 queries, i.e. ten 64-query tiles down to two 512-query ones
-    monkeypatch.setenv("INNR_GEMM_WAVES", waves)
+    from innr_amd import _lib
     rows, data = _corpus(70_000, 64, 31, uniform=True)
     vb = None
-    for metric in ("dot", "cos", "l2"):
-        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(600, 64, 777, uniform=True), 10,
-                        innr.KNN_MFMA)
+    with _lib.default_context().option("gemm_waves", int(waves)):
+        for metric in ("dot", "cos", "l2"):
+            vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(600, 64, 777, uniform=True), 10,
+                            innr.KNN_MFMA)

@@ -75,7 +75,8 @@ def _i8_dense(qc, queries):
     """test hook (outside include/innr_hip.h): the int8 engine's dense approximate scores + per-query constants"""
     import ctypes as C
     from innr_amd import _lib
-    fn = _lib.load().innrdbg_i8_scores
+    from conftest import hooks_lib
+    fn = hooks_lib().innrdbg_i8_scores
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
     q = np.ascontiguousarray(queries, np.float32)
@@ -91,13 +92,13 @@ def _i8_dense(qc, queries):
 
 @pytest.mark.parametrize("two_limb", ["0", "1"])
 @pytest.mark.parametrize("n,dim,nq", [(128, 64, 1), (300, 33, 5), (1000, 128, 70), (1025, 200, 300), (3000, 768, 33)])
-def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq, two_limb, monkeypatch):
+def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq, two_limb, ctx_option):
     """The int8 MFMA operand layout and the limb arithmetic, checked EXACTLY: with s = max|q| / T and t = round(q / s)
     (T = (R1 << S) + 2^(S-1) - 1, R1 from the dimension; S = 6: one limb on the matrix pipe + the exact low limb of
     v_dot4_i32_i8, S = 8: both limbs on the pipe), the kernel's V must equal sum_d (c_d - 128) t_d as integers -- asymmetric
     corpus and queries catch a transposed accumulator map or a k-order mismatch between the operands -- and its approximate
     score A V + B must stay within the engine's own bound E of the reference's asymmetric dot."""
-    monkeypatch.setenv("INNR_I8_TWO_LIMB", two_limb)
+    ctx_option("i8_two_limb", int(two_limb))
     shift = 8 if two_limb == "1" else 6
     alpha, offset = 2.0, -1.0
     codes = _codes(n, dim, 21, alpha, offset)
@@ -136,8 +137,8 @@ def test_i8_engine_dense_scores_are_the_limb_arithmetic_exactly(S, n, dim, nq, t
 @pytest.mark.parametrize("n,dim,nq,k,alpha,offset", [(300, 16, 20, 10, 2.0, -1.0), (10_000, 128, 100, 10, 2.0, -1.0),
                                                      (20_000, 96, 300, 100, 3.5, -0.25), (1030, 768, 17, 16, 2.0, -1.0),
                                                      (70_000, 40, 513, 5, 1.0, 0.0), (5000, 130, 9, 240, 2.0, -1.0)])
-def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_name, monkeypatch):
-    monkeypatch.setenv("INNR_I8_TWO_LIMB", "1" if engine_name == "int8-mfma-two-limbs" else "0")
+def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_name, ctx_option):
+    ctx_option("i8_two_limb", 1 if engine_name == "int8-mfma-two-limbs" else 0)
     engine = {"f32-mfma": innr.KNN_MFMA, "int8-mfma": innr.KNN_MFMA_I8, "int8-mfma-two-limbs": innr.KNN_MFMA_I8}[engine_name]
     codes = _codes(n, dim, 4, alpha, offset)
     qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
@@ -198,21 +199,26 @@ def test_i8_engine_longer_rows_and_many_tiles(S, innr, n, dim, nq, k):
     assert np.array_equal(i1[-40:], i3) and bits_equal(s1[-40:], s3)
 
 
-def test_i8_probe_run_hands_out_no_results(S, innr):
-    """INNR_I8H_PROBE bit 1 switches the int8 kernel's visits off to time its K-loop: such a call must fail, not return results"""
+def test_no_environment_variable_reaches_the_call_path(S, innr):
+    """The timing probes of the int8 kernel are compile-time switches of separate builds (tools/i8h_probe.py) and the tuning
+    options are read once, at innr_ctx_create: an environment variable set afterwards changes nothing -- in particular
+    INNR_I8H_PROBE, which in round 2 made the product library skip its visits, is inert."""
     import os
     p = S.QuantizationParams.from_range(-1.0, 1.0)
     qc = S.QuantizedCorpus.generate(200_000, 256, p, seed=2)
     qs = oracle.generate_uniform(600, 256, 3)
     ref_i, ref_s = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
+    e_i, e_s = qc.knn_multi(qs[:24], 10, engine=innr.KNN_EXACT)
+    assert np.array_equal(ref_i[:24], e_i) and bits_equal(ref_s[:24], e_s)
     os.environ["INNR_I8H_PROBE"] = "1"
+    os.environ["INNR_I8_TWO_LIMB"] = "1"
     try:
-        with pytest.raises(innr.InnrError):
-            qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
+        st = innr.KnnStats()
+        i2, s2 = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8, stats=st)
     finally:
         del os.environ["INNR_I8H_PROBE"]
-    i2, s2 = qc.knn_multi(qs, 10, engine=innr.KNN_MFMA_I8)
-    assert np.array_equal(i2, ref_i) and bits_equal(s2, ref_s)
+        del os.environ["INNR_I8_TWO_LIMB"]
+    assert np.array_equal(i2, ref_i) and bits_equal(s2, ref_s) and st.engine == innr.KNN_MFMA_I8
 
 
 def test_i8_engine_special_queries_and_params(S, innr):

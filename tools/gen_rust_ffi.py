@@ -16,7 +16,7 @@ SHIM = os.path.join(ROOT, "rust", "innr-hip", "src", "lib.rs")
 BEGIN, END = "        // ---- generated from include/innr_hip.h by tools/gen_rust_ffi.py: begin", "        // ---- generated: end"
 
 SCALAR = {"int": "c_int", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32", "innr_status": "c_int",
-          "uint8_t": "u8"}
+          "uint8_t": "u8", "long": "c_long"}
 OPAQUE = {"innr_ctx": "InnrCtx", "innr_batch": "InnrBatch", "innr_docs": "InnrDocs", "innr_comm": "InnrComm",
           "innr_knn_stats": "InnrKnnStats"}
 RUST_KEYWORDS = {"in", "type", "ref", "box", "move", "loop", "match", "mod", "fn", "use", "as", "where"}

@@ -8,7 +8,9 @@ queries]) with the corpus and the queries already resident in HBM; for N > 1 GPU
 range-partitioned, weak scaling: 10M vectors PER GPU) the step also includes the RCCL all-gather of the
 per-shard top-k and the merge. value = vectors scanned per second = Q * N_total / step time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: one process per GPU -- launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or, from a
+  bare shell, by bench.py itself (it starts that launcher as a child before touching a GPU and relays rank 0's line).
 
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the GEMM, timed live with HIP events on
 the stream it is launched on) and `cpu_baseline` (the CPU oracle = "port" of innr's portable path, single
@@ -103,6 +105,96 @@ def pmc_traffic(args):
             "algorithmic_bytes_per_launch": 4.0 * args.n_per_gpu * args.dim}
 
 
+def rehearse_cpu(args) -> int:
+    """--rehearse-cpu: the N-rank choreography of main() with a torch stand-in for the per-shard search (no HIP, no number)."""
+    import torch
+    import torch.distributed as dist
+    from innr_amd.dist import ShardedKnn, shard_range
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = args.n_per_gpu * world
+    start, count = shard_range(n_total, world, rank)
+    g = torch.Generator().manual_seed(1234)
+    corpus = torch.rand((n_total, args.dim), generator=g) * 2 - 1  # every rank draws the whole stream, keeps its range
+    shard = corpus[start:start + count]
+    queries = torch.rand((args.queries, args.dim), generator=torch.Generator().manual_seed(99)) * 2 - 1
+
+    def local_search(q, k, stats=None):
+        sc, idx = torch.topk(q @ shard.T, min(k, count), dim=1)
+        return idx.to(torch.int64) + start, sc
+
+    def merge(all_idx, all_sc, kout):  # [G, Q, kin] -> best kout by (score desc, global index asc)
+        gq = all_idx.permute(1, 0, 2).reshape(all_idx.shape[1], -1)
+        sq = all_sc.permute(1, 0, 2).reshape(all_sc.shape[1], -1).clone()
+        sq[gq < 0] = float("-inf")  # a shard with fewer than k vectors pads its block (INVALID_INDEX)
+        order = torch.argsort(gq, dim=1, stable=True)
+        gq, sq = torch.gather(gq, 1, order), torch.gather(sq, 1, order)
+        o2 = torch.argsort(sq, dim=1, descending=True, stable=True)[:, :kout]
+        return torch.gather(gq, 1, o2), torch.gather(sq, 1, o2)
+
+    sk = ShardedKnn(n_total, rank=rank, world=world, local_search=local_search, merge=merge) if world > 1 else None
+    step = (lambda: sk.search(queries, args.k)) if sk is not None else (lambda: local_search(queries, args.k))
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, sc = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    want_sc, want_idx = torch.topk(queries @ corpus.T, min(args.k, n_total), dim=1)
+    same = bool(torch.equal(idx, want_idx.to(torch.int64)))
+    if rank == 0:
+        print(json.dumps({"metric": "vectors scanned/sec (batch_knn_dot f32 d=768 k=10)", "value": None, "unit": "vectors/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "rehearsal": "cpu: torch stand-in engine, gloo; plumbing only, nothing measured",
+                          "sharded_result_equals_whole_corpus": same,
+                          "config": {"workload": f"rehearsal {args.n_per_gpu}x{args.dim} per rank, {args.queries} queries, k={args.k}"}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if same else 3
+
+
+def self_launch(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as so:  # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:  # rank 0 prints ONE JSON line; anything else the ranks print goes to stderr
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,13 +213,27 @@ def main() -> None:
                          "generate_embedding(dim, i), query j = generate_embedding(dim, N + j)), a one-parameter family with "
                          "hundreds of vectors within the f32 error bound of every k-th score -- the adversarial row: every "
                          "margin proof fails and every query is redone on the exact engine, 8 per corpus pass")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="plumbing rehearsal WITHOUT a GPU (tests/test_bench_launch.py): launcher, rendezvous (gloo), the ranks' range "
+                         "partition, ONE all-gather of the exchange blocks, merge, barrier / MAX timing and the JSON relay run as in "
+                         "the real thing; the per-shard search is a torch.matmul stand-in on a small corpus, nothing is measured "
+                         "(value = null) and no HIP code runs. Never a measurement path.")
     ap.add_argument("--engine", choices=["f32", "bf16", "i8"], default="f32",
                     help="f32: the MFMA GEMM filter on the f32 pipe (default, the judged configuration); bf16: the same "
                          "pipeline with the filter on the bf16 pipe (INNR_KNN_MFMA_BF16) -- identical results, reported "
                          "as a side measurement with its own roofline")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a bare shell: start the N ranks ourselves -- one fresh process per GPU under
+        # torch.distributed.run, BEFORE this process imports torch or touches a GPU -- relay rank 0's one JSON line and exit
+        # with the launcher's code (non-zero if any rank failed).
+        raise SystemExit(self_launch(args.gpus))
+
     import numpy as np
+
+    if args.rehearse_cpu:
+        raise SystemExit(rehearse_cpu(args))
 
     if not args.no_cpu_baseline and int(os.environ.get("RANK", "0")) == 0:
         import oracle
@@ -143,8 +249,6 @@ def main() -> None:
         local_rank = 0
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -186,9 +186,12 @@ float innr_mixed_dot_u8_f32(const float* a, const uint8_t* b, size_t n);
 /* corpus ingest on the device: codes of a resident f32 batch, out = quantize_u8 of every value (scalar.rs:212-225);
  * the new batch inherits the index base. */
 innr_status innr_batch_quantize_u8(innr_batch* f32_batch, float alpha, float offset, innr_batch** out);
-/* QuantizationParams::fit's range (scalar.rs:68-87) of a resident f32 batch: global min / max, NaN ignored;
- * *out_any = 0 when the batch holds no non-NaN value (the reference then returns alpha 1, offset 0). The order of
- * the reference's sequential scan decides between -0.0 and +0.0; here -0.0 < +0.0. */
+/* The range QuantizationParams::fit (scalar.rs:68-87) scans for, of a resident f32 batch: global min / max of the non-NaN
+ * values; *out_any = 0 when the batch holds none. The host side finishes `fit` exactly like the reference: no values at all
+ * -> {alpha 1, offset 0} (:69-74); otherwise from_range(min(f32::MAX, *out_min), max(f32::MIN, *out_max)) -- the reference's
+ * scan starts from (f32::MAX, f32::MIN) and `fit` has no min > max guard, so a non-empty ALL-NaN corpus gives
+ * from_range(f32::MAX, f32::MIN) = {alpha 1.0, offset 3.4028235e38}, not {1, 0} (innr_amd/scalar.py fit_batch, rust shim
+ * scalar::fit_batch). The order of the reference's sequential scan decides between -0.0 and +0.0; here -0.0 < +0.0. */
 innr_status innr_batch_minmax(innr_batch* f32_batch, float* out_min, float* out_max, int* out_any);
 /* QuantizationParams::fit_quantile's range (scalar.rs:104-139) of a resident f32 batch: the values at the reference's two
  * ranks (its own f32 index arithmetic, :131-134) of the FINITE values sorted by total_cmp, found by a radix select on the
@@ -325,6 +328,18 @@ innr_status innr_sharded_knn_dev(innr_comm* comm, innr_batch* shard, int metric,
 /* the same with host buffers (what the Rust shim's sharded::Comm::knn binds; out arrays sized Q*k) */
 innr_status innr_sharded_knn(innr_comm* comm, innr_batch* shard, int metric, const float* queries, size_t Q, size_t D, size_t k,
                              int engine, uint64_t* out_idx, float* out_score, size_t* out_k, innr_knn_stats* stats);
+/* maxsim over a document corpus range-partitioned across the ranks (maxsim.rs:96-137 per document; SURVEY.md 8e: "same scheme
+ * for maxsim"): innr_maxsim_topk on this rank's shard (documents [base, base + count): innr_docs_set_index_base), then the same
+ * exchange -- one block of 2 + k words per rank, ONE ncclAllGather, merge by (score, global document index). Query and outputs
+ * as in innr_maxsim_topk (host; identical on every rank; out arrays sized k). */
+innr_status innr_sharded_maxsim(innr_comm* comm, innr_docs* shard, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
+                                int engine, uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats);
+/* Failure semantics of the innr_sharded_* calls: the collective is SYMMETRIC. A rank whose local search fails (a filter copy that
+ * does not fit on that GPU, a dimension mismatch, ...) still takes part in the all-gather, with a block whose header says so;
+ * that rank returns its own status, every other rank INNR_E_RCCL naming the failed rank, none of them a result -- no rank waits
+ * in a collective its peer never entered. After a failed RCCL call itself the communicator is unusable: innr_comm_destroy
+ * then aborts it (ncclCommAbort) instead of destroying it. The shard sizes are learnt from the first exchange and cached in
+ * the communicator, so a steady-state call synchronises with the host once, at its end. */
 
 #ifdef __cplusplus
 }

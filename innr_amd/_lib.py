@@ -138,6 +138,7 @@ SIGNATURES = {
     "innr_merge_blocks_dev": (C.c_int, [_vp, C.c_int, _vp, _sz, _sz, _sz, _vp, _vp, _szp]),
     "innr_sharded_knn_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
     "innr_sharded_knn": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
+    "innr_sharded_maxsim": (C.c_int, [_vp, _vp, C.c_int, _vp, _sz, _sz, _sz, C.c_int, _vp, _vp, _szp, C.POINTER(KnnStats)]),
 }
 COMM_ID_BYTES = 128
 

@@ -85,6 +85,7 @@ struct innr_tuning {
     long rescore_all = 0;        // re-score every candidate (no progressive rounds)
     long maxsim_generic = 0;     // maxsim MFMA engine: the generic kernel instead of the tile-unrolled one
     long no_k_rule = 0;          // chip-wide bounds by the KP rule only (topk_dev.h): A/B of the k rule
+    long fail_local_search = 0;  // TEST switch of the sharded calls: this rank's local search reports a failure
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -94,6 +95,7 @@ static const TuneName kTuneNames[] = {
     {"i8_two_limb", &innr_tuning::i8_two_limb}, {"no_auto_bf16", &innr_tuning::no_auto_bf16},
     {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
+    {"fail_local_search", &innr_tuning::fail_local_search},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -3056,8 +3058,9 @@ static innr_status maxsim_topk_exact(innr_docs* d, int cosine, const float* qtok
     return INNR_OK;
 }
 
-innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
-                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+// to_host == false (the sharded call): the result stays on the device, at c->out_idx / c->out_score [*out_k]
+static innr_status maxsim_topk_impl(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
+                                    uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats, bool to_host) {
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!d || !out_k || (!qtok && Tq * dim)) return INNR_E_BAD_ARG;
     if (engine != INNR_KNN_AUTO && engine != INNR_KNN_EXACT && engine != INNR_KNN_MFMA) return INNR_E_BAD_ARG;
@@ -3070,7 +3073,7 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     }
     if (d->ndocs == 0 || k == 0) return INNR_OK;
     const size_t kout = std::min(k, d->ndocs);  // beyond INNR_MAX_K: the exact engine sorts all document scores
-    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
+    if (to_host && (!out_doc || !out_score)) return INNR_E_BAD_ARG;
     const bool eligible = maxsim_mfma_eligible(d, Tq) && kout <= INNR_MAX_K && pick_kp(kout, 16) <= 256;
     if (engine == INNR_KNN_MFMA && !eligible) {
         set_error("maxsim MFMA engine needs T > 16, dim %% 8 == 0, 8 <= dim <= 512, a non-empty query and k <= 240");
@@ -3106,8 +3109,10 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
     }
     INNR_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     INNR_TRY(check_errflag(c));
-    INNR_HIP_CHECK(copy_out(c, out_doc, c->out_idx.p, kout * sizeof(uint64_t)));
-    INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, kout * sizeof(float)));
+    if (to_host) {
+        INNR_HIP_CHECK(copy_out(c, out_doc, c->out_idx.p, kout * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, kout * sizeof(float)));
+    }
     INNR_HIP_CHECK(ctx_sync(c));
     *out_k = kout;
     if (stats) {
@@ -3120,6 +3125,11 @@ innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) stats->total_ms = ms;
     }
     return INNR_OK;
+}
+
+innr_status innr_maxsim_topk(innr_docs* d, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k, int engine,
+                             uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    return maxsim_topk_impl(d, cosine, qtok, Tq, dim, k, engine, out_doc, out_score, out_k, stats, true);
 }
 
 // Several queries against the same corpus in one call (an addition: the reference scores one (query, document) pair
@@ -3458,6 +3468,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: used to tear down a communicator whose collective failed
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -3478,6 +3489,7 @@ static RcclApi* load_rccl() {
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
         api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
@@ -3518,33 +3530,88 @@ __global__ void pack_topk_kernel(const uint64_t* __restrict__ idx, const float* 
     block[2 + t] = e;
 }
 
+// A rank whose local search FAILED still takes part in the all-gather -- with this block: header word 1 = all ones (no shard holds
+// 2^64 - 1 vectors), word 0 = the negated status, no candidates. Every rank then sees the flag in the gathered headers and returns
+// an error instead of waiting in a collective its peer never enters.
+constexpr uint64_t kBlockFailed = ~0ull;
+__global__ void pack_error_kernel(uint64_t code, uint32_t Q, uint32_t k, uint64_t* __restrict__ block) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        block[0] = code;
+        block[1] = kBlockFailed;
+    }
+    if (t < (size_t)Q * k) block[2 + t] = 0xFFFFFFFFull;
+}
+
 // G gathered blocks -> best kout per query; one wave per query, rank counting on (preference, global index) like
-// merge_topk_kernel (kernels_topk.h)
+// merge_topk_kernel (kernels_topk.h). The query's G*k candidates are staged in LDS once (dynamic shared memory: total x
+// {u32 preference, u64 global index}); beyond `lds_entries` they are re-read from global memory per comparison (L2-resident).
+// err (nullable): bit 0 set when a block's header carries the failure flag (err[1 + g] = its code), bit 1 when the headers'
+// vector counts do not add up to `expect_total` (the caller's cached figure is stale).
 __global__ __launch_bounds__(64) void merge_blocks_kernel(const uint64_t* __restrict__ blocks, uint32_t G, uint32_t Q, uint32_t k,
                                                           uint32_t kout, bool smaller_is_better, uint64_t* __restrict__ out_idx,
-                                                          float* __restrict__ out_score) {
+                                                          float* __restrict__ out_score, uint32_t lds_entries, uint64_t expect_total,
+                                                          uint32_t* __restrict__ err) {
+    extern __shared__ uint64_t merge_lds[];
     const uint32_t q = blockIdx.x;
     const uint32_t total = G * k;
     const size_t words = 2 + (size_t)Q * k;
     const int lane = threadIdx.x;
-    for (uint32_t c = lane; c < total; c += 64) {
+    if (err && q == 0) {
+        uint64_t sum = 0;
+        bool failed = false;
+        for (uint32_t g = lane; g < G; g += 64) {
+            const uint64_t n = blocks[(size_t)g * words + 1];
+            if (n == kBlockFailed) {
+                failed = true;
+                err[1 + (g < 62 ? g : 62)] = (uint32_t)blocks[(size_t)g * words];
+            } else {
+                sum += n;
+            }
+        }
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor((unsigned long long)sum, off, 64);
+        if (__any(failed)) { if (lane == 0) atomicOr(err, 1u); }
+        else if (expect_total != sum && lane == 0) atomicOr(err, 2u);
+    }
+    const bool staged = total <= lds_entries;
+    uint64_t* s_idx = merge_lds;                                            // [total]
+    uint32_t* s_pref = reinterpret_cast<uint32_t*>(merge_lds + (staged ? total : 0));  // [total]
+    auto fetch = [&](uint32_t c, uint64_t* gi, uint32_t* pf, float* sf) {
         const uint32_t g = c / k, r = c % k;
         const uint64_t* blk = blocks + (size_t)g * words;
         const uint64_t e = blk[2 + (size_t)q * k + r];
-        const bool valid = (uint32_t)e != 0xFFFFFFFFu;
-        const uint64_t my_i = valid ? blk[0] + (uint32_t)e : ~0ull;
-        const float my_sf = __uint_as_float((uint32_t)(e >> 32));
-        const uint32_t my_p = !valid ? 0u : (smaller_is_better ? ~f32_ord(my_sf) : f32_ord(my_sf));
+        const bool valid = (uint32_t)e != 0xFFFFFFFFu && blk[1] != kBlockFailed;
+        *gi = valid ? blk[0] + (uint32_t)e : ~0ull;
+        *sf = __uint_as_float((uint32_t)(e >> 32));
+        *pf = !valid ? 0u : (smaller_is_better ? ~f32_ord(*sf) : f32_ord(*sf));
+    };
+    if (staged) {
+        for (uint32_t c = lane; c < total; c += 64) {
+            float sf;
+            fetch(c, &s_idx[c], &s_pref[c], &sf);
+        }
+        __syncthreads();
+    }
+    for (uint32_t c = lane; c < total; c += 64) {
+        uint64_t my_i;
+        uint32_t my_p;
+        float my_sf;
+        fetch(c, &my_i, &my_p, &my_sf);
         uint32_t rank = 0;
-        for (uint32_t o = 0; o < total; ++o) {
-            const uint32_t g2 = o / k, r2 = o % k;
-            const uint64_t* blk2 = blocks + (size_t)g2 * words;
-            const uint64_t e2 = blk2[2 + (size_t)q * k + r2];
-            const bool v2 = (uint32_t)e2 != 0xFFFFFFFFu;
-            const uint64_t i2 = v2 ? blk2[0] + (uint32_t)e2 : ~0ull;
-            const float sf = __uint_as_float((uint32_t)(e2 >> 32));
-            const uint32_t p = !v2 ? 0u : (smaller_is_better ? ~f32_ord(sf) : f32_ord(sf));
-            rank += (p > my_p || (p == my_p && (i2 < my_i || (i2 == my_i && o < c)))) ? 1u : 0u;
+        if (staged) {
+            for (uint32_t o = 0; o < total; ++o) {
+                const uint32_t p = s_pref[o];
+                const uint64_t i2 = s_idx[o];
+                rank += (p > my_p || (p == my_p && (i2 < my_i || (i2 == my_i && o < c)))) ? 1u : 0u;
+            }
+        } else {
+            for (uint32_t o = 0; o < total; ++o) {
+                uint64_t i2;
+                uint32_t p;
+                float sf;
+                fetch(o, &i2, &p, &sf);
+                rank += (p > my_p || (p == my_p && (i2 < my_i || (i2 == my_i && o < c)))) ? 1u : 0u;
+            }
         }
         if (rank < kout) {
             out_idx[(size_t)q * kout + rank] = my_i;
@@ -3561,6 +3628,11 @@ struct innr_comm {
     bool owned = false;
     int rank = 0, world = 1;
     DevBuf block, all, loc_idx, loc_sc, hdr;  // this rank's block, the gathered blocks, the local top-k
+    // Vectors in all shards, learnt from the first exchange's headers: shard sizes are fixed once the shards are attached, so
+    // later calls launch the merge without a host round trip; the merge kernel re-checks the sum and flags a stale figure.
+    bool have_total = false;
+    uint64_t total = 0;
+    bool broken = false;  // a collective failed: the communicator is aborted, not destroyed
 };
 
 extern "C" {
@@ -3625,7 +3697,8 @@ void innr_comm_destroy(innr_comm* cm) {
         }
         if (cm->owned && cm->comm) {
             RcclApi* api = load_rccl();
-            if (api) (void)api->CommDestroy(cm->comm);
+            if (api && cm->broken && api->CommAbort) (void)api->CommAbort(cm->comm);  // peers may never enter a matching destroy
+            else if (api) (void)api->CommDestroy(cm->comm);
         }
         DevBuf* bufs[] = {&cm->block, &cm->all, &cm->loc_idx, &cm->loc_sc, &cm->hdr};
         for (DevBuf* b : bufs) b->release();
@@ -3655,9 +3728,44 @@ innr_status innr_allgather_topk_dev(innr_comm* cm, const uint64_t* d_block, size
     if (!api) return INNR_E_RCCL;
     INNR_ENTER(cm->ctx);
     const size_t bytes = innr_topk_block_words(Q, k) * sizeof(uint64_t);
-    INNR_RCCL_CHECK(api, api->AllGather(d_block, d_all_blocks, bytes, ncclUint8, cm->comm, cm->ctx->stream));
+    const ncclResult_t r = api->AllGather(d_block, d_all_blocks, bytes, ncclUint8, cm->comm, cm->ctx->stream);
+    if (r != ncclSuccess) {
+        cm->broken = true;
+        set_error("ncclAllGather failed: %s", api->GetErrorString(r));
+        return INNR_E_RCCL;
+    }
     return INNR_OK;
 }
+
+}  // extern "C"
+
+namespace innr {
+constexpr uint32_t kMergeErrWord = 96;  // c->flags words [96, 160): the merge kernel's report (flag, then one code per rank)
+// launch the merge; LDS staging for up to 3072 candidates per query (36 KiB)
+static innr_status launch_merge_blocks(innr_ctx* c, int metric, const uint64_t* d_all, size_t G, size_t Q, size_t k, size_t kout,
+                                       uint64_t* d_out_idx, float* d_out_score, uint64_t expect_total, bool report) {
+    const uint32_t lds_entries = 3072;
+    const size_t total = G * k;
+    const size_t shmem = total <= lds_entries ? total * 12 + 8 : 0;
+    uint32_t* err = report ? c->flags.as<uint32_t>() + kMergeErrWord : nullptr;
+    if (report) INNR_HIP_CHECK(hipMemsetAsync(err, 0, 64 * sizeof(uint32_t), c->stream));
+    merge_blocks_kernel<<<(unsigned)Q, 64, shmem, c->stream>>>(d_all, (uint32_t)G, (uint32_t)Q, (uint32_t)k, (uint32_t)kout,
+                                                             metric == INNR_METRIC_L2SQ, d_out_idx, d_out_score, lds_entries,
+                                                             expect_total, err);
+    INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+static innr_status failed_rank_error(const uint64_t* hdr, size_t G) {
+    for (size_t g = 0; g < G; ++g)
+        if (hdr[2 * g + 1] == kBlockFailed) {
+            set_error("rank %zu of the sharded call failed its local search (status %d): no rank has a result", g, -(int)(int64_t)hdr[2 * g]);
+            return INNR_E_RCCL;
+        }
+    return INNR_OK;
+}
+}  // namespace innr
+
+extern "C" {
 
 innr_status innr_merge_blocks_dev(innr_ctx* ctx, int metric, const uint64_t* d_all_blocks, size_t G, size_t Q, size_t k,
                                   uint64_t* d_out_idx, float* d_out_score, size_t* out_k) {
@@ -3666,23 +3774,92 @@ innr_status innr_merge_blocks_dev(innr_ctx* ctx, int metric, const uint64_t* d_a
     if (Q == 0 || k == 0) return INNR_OK;
     if (G * k >= 0xFFFFFFFFull || Q >= 0xFFFFFFFFull) return INNR_E_UNSUPPORTED;
     INNR_ENTER(ctx);
-    // k' = min(k, vectors in all shards): the shard sizes travel in the blocks' headers
+    // k' = min(k, vectors in all shards): the shard sizes travel in the blocks' headers (a caller without an innr_comm has
+    // nowhere to cache them: one host round trip; innr_sharded_* caches them in its communicator)
     const size_t words = innr_topk_block_words(Q, k);
     std::vector<uint64_t> hdr(2 * G);
     INNR_HIP_CHECK(hipMemcpy2DAsync(hdr.data(), 16, d_all_blocks, words * sizeof(uint64_t), 16, G, hipMemcpyDeviceToHost, ctx->stream));
     INNR_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    INNR_TRY(failed_rank_error(hdr.data(), G));  // a rank that failed locally says so in its header: every rank returns an error
     uint64_t total = 0;
     for (size_t g = 0; g < G; ++g) total += hdr[2 * g + 1];
     const size_t kout = (size_t)std::min<uint64_t>(k, total);
     if (kout == 0) return INNR_OK;
     if (!d_out_idx || !d_out_score) return INNR_E_BAD_ARG;
-    merge_blocks_kernel<<<(unsigned)Q, 64, 0, ctx->stream>>>(d_all_blocks, (uint32_t)G, (uint32_t)Q, (uint32_t)k, (uint32_t)kout,
-                                                            metric == INNR_METRIC_L2SQ, d_out_idx, d_out_score);
-    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(launch_merge_blocks(ctx, metric, d_all_blocks, G, Q, k, kout, d_out_idx, d_out_score, total, false));
     INNR_HIP_CHECK(ctx_sync(ctx));
     *out_k = kout;
     return INNR_OK;
 }
+
+}  // extern "C"
+
+namespace innr {
+// Exchange + merge of the sharded calls. local_status: what this rank's local search returned (its results, if any, are at
+// cm->loc_idx / cm->loc_sc with `kin` entries per query). The collective is SYMMETRIC: a failing rank gathers an error block.
+static innr_status sharded_exchange(innr_comm* cm, innr_status local_status, int metric, uint64_t index_base, uint64_t shard_n,
+                                    size_t Q, size_t kin, size_t k, uint64_t* d_out_idx, float* d_out_score, size_t* out_k) {
+    innr_ctx* c = cm->ctx;
+    const size_t words = innr_topk_block_words(Q, k);
+    char local_msg[512];
+    if (local_status != INNR_OK) {
+        snprintf(local_msg, sizeof(local_msg), "%s", innr_last_error());
+        const size_t n = std::max<size_t>(Q * k, 1);
+        pack_error_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>((uint64_t)(int64_t)(-local_status), (uint32_t)Q, (uint32_t)k,
+                                                                            cm->block.as<uint64_t>());
+        INNR_HIP_CHECK(hipGetLastError());
+    } else {
+        INNR_TRY(innr_topk_pack_dev(c, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), index_base, shard_n, Q, kin, k,
+                                    cm->block.as<uint64_t>()));
+    }
+    INNR_TRY(innr_allgather_topk_dev(cm, cm->block.as<uint64_t>(), Q, k, cm->all.as<uint64_t>()));
+    const size_t G = (size_t)cm->world;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!cm->have_total) {  // first exchange (or the cached figure went stale): learn the shard sizes from the headers
+            std::vector<uint64_t> hdr(2 * G);
+            INNR_HIP_CHECK(hipMemcpy2DAsync(hdr.data(), 16, cm->all.p, words * sizeof(uint64_t), 16, G, hipMemcpyDeviceToHost, c->stream));
+            INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (local_status != INNR_OK) {
+                set_error("%s", local_msg);
+                return local_status;
+            }
+            INNR_TRY(failed_rank_error(hdr.data(), G));
+            cm->total = 0;
+            for (size_t g = 0; g < G; ++g) cm->total += hdr[2 * g + 1];
+            cm->have_total = true;
+        }
+        const size_t kout = (size_t)std::min<uint64_t>(k, cm->total);
+        if (kout && (!d_out_idx || !d_out_score)) return INNR_E_BAD_ARG;
+        if (kout) INNR_TRY(launch_merge_blocks(c, metric, cm->all.as<uint64_t>(), G, Q, k, kout, d_out_idx, d_out_score, cm->total, true));
+        uint32_t rep[64] = {0};
+        if (kout) INNR_HIP_CHECK(copy_out(c, rep, c->flags.as<uint32_t>() + kMergeErrWord, sizeof(rep)));
+        INNR_HIP_CHECK(ctx_sync(c));  // the one synchronisation of the call: results complete, the merge's report on the host
+        if (local_status != INNR_OK) {
+            set_error("%s", local_msg);
+            return local_status;
+        }
+        if (rep[0] & 1u) {
+            for (size_t g = 0; g < G && g < 63; ++g)
+                if (rep[1 + g]) {
+                    set_error("rank %zu of the sharded call failed its local search (status %d): no rank has a result", g, -(int)rep[1 + g]);
+                    return INNR_E_RCCL;
+                }
+            set_error("a rank of the sharded call failed its local search: no rank has a result");
+            return INNR_E_RCCL;
+        }
+        if (rep[0] & 2u) {  // shard sizes changed since they were cached: read them again and merge once more
+            cm->have_total = false;
+            continue;
+        }
+        *out_k = kout;
+        return INNR_OK;
+    }
+    set_error("internal: shard sizes changed during a sharded call");
+    return INNR_E_HIP;
+}
+}  // namespace innr
+
+extern "C" {
 
 innr_status innr_sharded_knn_dev(innr_comm* cm, innr_batch* shard, int metric, const float* d_queries, size_t Q, size_t D,
                                  size_t k, int engine, uint64_t* d_out_idx, float* d_out_score, size_t* out_k,
@@ -3694,30 +3871,31 @@ innr_status innr_sharded_knn_dev(innr_comm* cm, innr_batch* shard, int metric, c
     }
     *out_k = 0;
     if (Q == 0 || k == 0) return INNR_OK;  // nothing to exchange (every rank takes this branch: same arguments)
-    if (k > ((size_t)1 << 20)) {
-        set_error("innr_sharded_knn_dev: k=%zu: at most 2^20 candidates per shard and query are exchanged", k);
-        return INNR_E_UNSUPPORTED;
+    if (k > ((size_t)1 << 20) || Q * k >= 0xFFFFFFFFull) {
+        set_error("innr_sharded_knn_dev: k=%zu: at most 2^20 candidates per shard and query (and 2^32 per call) are exchanged", k);
+        return INNR_E_UNSUPPORTED;  // (the same on every rank: same arguments)
     }
     innr_ctx* c = cm->ctx;
     INNR_ENTER(c);
     const size_t words = innr_topk_block_words(Q, k);
+    // Workspace failures are rank-local too, but without the block there is nothing to gather: they are returned at once
+    // (a few MB against a shard of tens of GB; the peers' collective then times out in RCCL, INNR_E_RCCL there).
     INNR_TRY(cm->loc_idx.ensure(Q * k * sizeof(uint64_t)));
     INNR_TRY(cm->loc_sc.ensure(Q * k * sizeof(float)));
     INNR_TRY(cm->block.ensure(words * sizeof(uint64_t)));
     INNR_TRY(cm->all.ensure((size_t)cm->world * words * sizeof(uint64_t)));
     size_t kin = 0;
     const bool u8 = shard->C8 != nullptr && shard->V == nullptr;
-    // the local search; a dimension mismatch is reported before anything is exchanged (it is the same on every rank)
-    if (u8)
-        INNR_TRY(innr_batch_knn_u8_dev(shard, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin, stats));
-    else
-        INNR_TRY(innr_batch_knn_dev(shard, metric, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin,
-                                    stats));
-    INNR_TRY(innr_topk_pack_dev(c, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), shard->index_base, shard->N, Q, kin, k,
-                                cm->block.as<uint64_t>()));
-    INNR_TRY(innr_allgather_topk_dev(cm, cm->block.as<uint64_t>(), Q, k, cm->all.as<uint64_t>()));
-    return innr_merge_blocks_dev(c, u8 ? INNR_METRIC_DOT : metric, cm->all.as<uint64_t>(), (size_t)cm->world, Q, k, d_out_idx,
-                                 d_out_score, out_k);
+    // The local search. Its failure -- a filter copy that does not fit on THIS rank, a broken list invariant, a dimension
+    // mismatch -- does not end the call here: the rank gathers an error block, and every rank returns an error.
+    innr_status ls;
+    if (u8) ls = innr_batch_knn_u8_dev(shard, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin, stats);
+    else ls = innr_batch_knn_dev(shard, metric, d_queries, Q, D, k, engine, cm->loc_idx.as<uint64_t>(), cm->loc_sc.as<float>(), &kin, stats);
+    if (ls == INNR_OK && c->tune.fail_local_search) {  // test switch: this rank pretends its local search failed
+        set_error("local search failed on request (option fail_local_search)");
+        ls = INNR_E_HIP;
+    }
+    return sharded_exchange(cm, ls, u8 ? INNR_METRIC_DOT : metric, shard->index_base, shard->N, Q, kin, k, d_out_idx, d_out_score, out_k);
 }
 
 innr_status innr_sharded_knn(innr_comm* cm, innr_batch* shard, int metric, const float* queries, size_t Q, size_t D, size_t k,
@@ -3740,6 +3918,55 @@ innr_status innr_sharded_knn(innr_comm* cm, innr_batch* shard, int metric, const
         INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, Q * *out_k * sizeof(float)));
         INNR_HIP_CHECK(ctx_sync(c));
     }
+    return INNR_OK;
+}
+
+// maxsim over a document corpus range-partitioned across the ranks (maxsim.rs:96-137 per document; SURVEY.md 8e "same scheme
+// for maxsim"): this rank's innr_maxsim_topk on its shard, then the SAME exchange -- one block of 2 + k words, one ncclAllGather,
+// one merge by (score, global document index). The query (host, [Tq*dim], identical on every rank) and the outputs (host, [k'])
+// follow innr_maxsim_topk.
+innr_status innr_sharded_maxsim(innr_comm* cm, innr_docs* shard, int cosine, const float* qtok, size_t Tq, size_t dim, size_t k,
+                                int engine, uint64_t* out_doc, float* out_score, size_t* out_k, innr_knn_stats* stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!cm || !shard || !out_k || shard->ctx != cm->ctx) {
+        set_error("innr_sharded_maxsim: null comm / shard, or the shard lives on another context");
+        return INNR_E_BAD_ARG;
+    }
+    *out_k = 0;
+    if (k == 0) return INNR_OK;
+    if (k > ((size_t)1 << 20)) {
+        set_error("innr_sharded_maxsim: k=%zu: at most 2^20 candidates per shard are exchanged", k);
+        return INNR_E_UNSUPPORTED;
+    }
+    if (!out_doc || !out_score) return INNR_E_BAD_ARG;
+    innr_ctx* c = cm->ctx;
+    INNR_ENTER(c);
+    const size_t words = innr_topk_block_words(1, k);
+    INNR_TRY(cm->loc_idx.ensure(k * sizeof(uint64_t)));
+    INNR_TRY(cm->loc_sc.ensure(k * sizeof(float)));
+    INNR_TRY(cm->block.ensure(words * sizeof(uint64_t)));
+    INNR_TRY(cm->all.ensure((size_t)cm->world * words * sizeof(uint64_t)));
+    INNR_TRY(c->out_idx.ensure(k * sizeof(uint64_t)));
+    INNR_TRY(c->out_score.ensure(k * sizeof(float)));
+    size_t kin = 0;
+    innr_status ls = maxsim_topk_impl(shard, cosine, qtok, Tq, dim, k, engine, nullptr, nullptr, &kin, stats, false);
+    if (ls == INNR_OK && c->tune.fail_local_search) {
+        set_error("local search failed on request (option fail_local_search)");
+        ls = INNR_E_HIP;
+    }
+    if (ls == INNR_OK && kin) {  // an empty shard (ndocs == 0) returns kin = 0 and gathers a block without candidates
+        INNR_HIP_CHECK(hipMemcpyAsync(cm->loc_idx.p, c->out_idx.p, kin * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+        INNR_HIP_CHECK(hipMemcpyAsync(cm->loc_sc.p, c->out_score.p, kin * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    size_t kout = 0;
+    INNR_TRY(sharded_exchange(cm, ls, INNR_METRIC_DOT, shard->index_base, shard->ndocs, 1, kin, k, c->out_idx.as<uint64_t>(),
+                              c->out_score.as<float>(), &kout));
+    if (kout) {
+        INNR_HIP_CHECK(copy_out(c, out_doc, c->out_idx.p, kout * sizeof(uint64_t)));
+        INNR_HIP_CHECK(copy_out(c, out_score, c->out_score.p, kout * sizeof(float)));
+        INNR_HIP_CHECK(ctx_sync(c));
+    }
+    *out_k = kout;
     return INNR_OK;
 }
 

@@ -60,9 +60,21 @@ class Comm:
         """Rank 0 draws the id, torch.distributed carries it to the other ranks (bootstrap only), every rank joins."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        # Rank 0 ALWAYS takes part in the broadcast -- with the id, or with the reason it has none (no librccl, a missing
+        # symbol): the other ranks are already waiting in it, and a rank 0 that raised first would leave them there while it
+        # moves on to its caller's next collective. After the broadcast every rank raises the same error.
+        uid, err = None, None
+        if rank == 0:
+            try:
+                uid = cls.unique_id()
+            except Exception as exc:
+                err = f"{type(exc).__name__}: {exc}"
+        box = [(uid, err)]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(ctx, rank, world, box[0])
+        uid, err = box[0]
+        if uid is None:
+            raise _lib.InnrError(_lib.E_RCCL, f"rank 0 could not draw a communicator id: {err}")
+        return cls(ctx, rank, world, uid)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -258,11 +270,28 @@ class ShardedKnn:
         self.merge = _gpu_merge(corpus._ctx, METRIC_DOT)
         self._attach(corpus, corpus._ctx, METRIC_DOT)
         self._one_query = True
+        self._docs = (corpus, bool(cosine), engine)
 
     def search(self, queries, k: int, stats: Optional[KnnStats] = None):
         """queries: [Q, D] tensor on this rank's device (identical on every rank). Returns the global top-k:
         (indices int64 [Q, k'], scores float32 [Q, k']) with k' = min(k, n_total), identical on every rank."""
         import torch
+        if self.comm is not None and getattr(self, "_docs", None) is not None:
+            # maxsim through the library's exchange (innr_sharded_maxsim): the query and the result are host arrays, like
+            # innr_maxsim_topk's; the local top-k, the blocks and the merge stay on the device
+            corpus, cosine, engine = self._docs
+            q = np.ascontiguousarray(queries.detach().cpu().numpy() if hasattr(queries, "detach") else queries, np.float32)
+            tq, dim = q.shape
+            kk = max(int(k), 1)
+            out_i = np.empty(kk, np.uint64)
+            out_s = np.empty(kk, np.float32)
+            out_k = C.c_size_t(0)
+            st = stats if stats is not None else KnnStats()
+            check(load().innr_sharded_maxsim(self.comm._h, corpus._h, int(cosine), q.ctypes.data, tq, dim, int(k), engine,
+                                             out_i.ctypes.data, out_s.ctypes.data, C.byref(out_k), C.byref(st)))
+            r = int(out_k.value)
+            dev = queries.device if hasattr(queries, "device") else "cpu"
+            return (torch.from_numpy(out_i[:r].astype(np.int64)).reshape(1, r).to(dev), torch.from_numpy(out_s[:r].copy()).reshape(1, r).to(dev))
         if self.comm is not None and self._shard is not None:
             # the whole sharded call behind the boundary: local search + pack + ONE ncclAllGather + merge, ctx stream
             obj, metric, engine = self._shard
@@ -279,12 +308,24 @@ class ShardedKnn:
                                               C.byref(st)))
             r = int(out_k.value)
             return out_i.reshape(-1)[:nq * r].reshape(nq, r), out_s.reshape(-1)[:nq * r].reshape(nq, r)
-        idx, sc = self.local_search(queries, k, stats) if stats is not None else self.local_search(queries, k)
         nq = 1 if getattr(self, "_one_query", False) else queries.shape[0]
         kk = max(int(k), 1)
+        # The exchange is SYMMETRIC (include/innr_hip.h, failure semantics of innr_sharded_*): a rank whose local search fails
+        # still gathers -- a block whose header says so -- and every rank raises, instead of one rank leaving the others in
+        # the collective.
+        failure = None
+        try:
+            idx, sc = self.local_search(queries, k, stats) if stats is not None else self.local_search(queries, k)
+        except Exception as exc:
+            failure = exc
         # ONE exchange step: all-gather of every rank's block (gloo in the CPU tests; through the host when ranks of a
         # rehearsal share one GPU, where RCCL cannot run): (2 + Q*k) * 8 bytes per rank
-        if idx.is_cuda:
+        if failure is not None:
+            block = torch.full((2 + nq * kk,), _NO_CANDIDATE, dtype=torch.int64)
+            block[0], block[1] = int(getattr(failure, "status", _lib.E_HIP)) * -1, -1  # word 1 all ones: "this rank failed"
+            if getattr(queries, "is_cuda", False):
+                block = block.to(queries.device)
+        elif idx.is_cuda:
             block = gpu_pack_block(self._ctx, idx, sc, self.start, self.count, kk)
         else:
             block = pack_block_host(idx, sc, self.start, self.count, kk)
@@ -292,6 +333,12 @@ class ShardedKnn:
         send = block.cpu() if via_host else block
         blocks = torch.empty((self.world, send.numel()), dtype=torch.int64, device=send.device)
         self.dist.all_gather(list(blocks.unbind(0)), send, group=self.group)
+        if failure is not None:
+            raise failure
+        failed = [g for g in range(self.world) if int(blocks[g, 1]) == -1]
+        if failed:
+            raise _lib.InnrError(_lib.E_RCCL, f"rank {failed[0]} of the sharded call failed its local search "
+                                              f"(status {-int(blocks[failed[0], 0])}): no rank has a result")
         if idx.is_cuda:
             return gpu_merge_blocks(self._ctx, self._metric, blocks.to(idx.device), nq, kk)
         all_i, all_s, total = unpack_blocks_host(blocks, nq, kk)

@@ -34,7 +34,8 @@ class QuantizationParams:
 
     @staticmethod
     def from_range(mn: float, mx: float) -> "QuantizationParams":  # scalar.rs:54-60
-        alpha = F(mx) - F(mn)
+        with np.errstate(over="ignore", invalid="ignore"):  # f32::MIN - f32::MAX = -inf, inf - inf = NaN: both "not > 0"
+            alpha = F(mx) - F(mn)
         return QuantizationParams(float(alpha) if alpha > 0 else 1.0, float(F(mn)))
 
     @staticmethod
@@ -287,11 +288,18 @@ class QuantizedCorpus:
 
 def fit_batch(batch) -> QuantizationParams:
     """QuantizationParams::fit (scalar.rs:68-87) over every value of a device-resident f32 VerticalBatch."""
+    if batch.num_vectors() * batch.dimension() == 0:  # scalar.rs:69-74: no values at all
+        return QuantizationParams(1.0, 0.0)
     mn, mx, any_ = C.c_float(0.0), C.c_float(0.0), C.c_int(0)
     check(load().innr_batch_minmax(batch._h, C.byref(mn), C.byref(mx), C.byref(any_)))
-    if not any_.value:  # empty (scalar.rs:69-74); an all-NaN corpus leaves min > max in the reference: same result
-        return QuantizationParams(1.0, 0.0)
-    return QuantizationParams.from_range(float(mn.value), float(mx.value))
+    # The reference's scan starts from (f32::MAX, f32::MIN) and only ever takes `v < min` / `v > max` (scalar.rs:76-85), and
+    # `fit` -- unlike fit_vectors (:156-161) -- has no min > max guard: a non-empty all-NaN corpus therefore yields
+    # from_range(f32::MAX, f32::MIN) = {alpha 1.0, offset 3.4028235e38}, and a corpus whose only non-NaN values are +inf
+    # keeps min = f32::MAX (inf < MAX is false). The device reports the true extrema of the non-NaN values: clamp them the same way.
+    lo, hi = F(3.4028235e38), F(-3.4028235e38)
+    if any_.value:
+        lo, hi = min(lo, F(mn.value)), max(hi, F(mx.value))
+    return QuantizationParams.from_range(float(lo), float(hi))
 
 
 def fit_quantile_batch(batch, quantile: float) -> QuantizationParams:

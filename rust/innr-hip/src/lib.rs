@@ -113,6 +113,7 @@ pub mod ffi {
         pub fn innr_merge_blocks_dev(ctx: *mut InnrCtx, metric: c_int, d_all_blocks: *const u64, g: usize, q: usize, k: usize, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize) -> c_int;
         pub fn innr_sharded_knn_dev(comm: *mut InnrComm, shard: *mut InnrBatch, metric: c_int, d_queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, d_out_idx: *mut u64, d_out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
         pub fn innr_sharded_knn(comm: *mut InnrComm, shard: *mut InnrBatch, metric: c_int, queries: *const f32, q: usize, d: usize, k: usize, engine: c_int, out_idx: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
+        pub fn innr_sharded_maxsim(comm: *mut InnrComm, shard: *mut InnrDocs, cosine: c_int, qtok: *const f32, tq: usize, dim: usize, k: usize, engine: c_int, out_doc: *mut u64, out_score: *mut f32, out_k: *mut usize, stats: *mut InnrKnnStats) -> c_int;
         // ---- generated: end
     }
 }
@@ -374,6 +375,23 @@ pub mod scalar {
             let alpha = max - min;
             Self { alpha: if alpha > 0.0 { alpha } else { 1.0 }, offset: min }
         }
+        /// scalar.rs:68-87: the range of the values that compare (NaN never does), starting from (f32::MAX, f32::MIN); no
+        /// values at all -> {1, 0}. (No min > max guard, like the reference: all-NaN input gives {1.0, f32::MAX}.)
+        #[must_use] pub fn fit(values: &[f32]) -> Self {
+            if values.is_empty() { return Self { alpha: 1.0, offset: 0.0 }; }
+            let (lo, hi) = values.iter().fold((f32::MAX, f32::MIN), |(lo, hi), &v| (if v < lo { v } else { lo }, if v > hi { v } else { hi }));
+            Self::from_range(lo, hi)
+        }
+        /// `fit` over every value of a corpus resident on the GPU (innr_batch_minmax: the non-NaN extrema, clamped to the
+        /// reference's starting values -- see include/innr_hip.h)
+        #[must_use] pub fn fit_batch(batch: &batch::VerticalBatch) -> Self {
+            if batch.num_vectors() * batch.dimension() == 0 { return Self { alpha: 1.0, offset: 0.0 }; }
+            let (mut mn, mut mx, mut any) = (0f32, 0f32, 0);
+            check(unsafe { ffi::innr_batch_minmax(batch.handle(), &mut mn, &mut mx, &mut any) });
+            let (mut lo, mut hi) = (f32::MAX, f32::MIN);
+            if any != 0 { if mn < lo { lo = mn; } if mx > hi { hi = mx; } }
+            Self::from_range(lo, hi)
+        }
     }
 
     /// scalar.rs:171-208
@@ -453,6 +471,9 @@ pub mod maxsim {
     unsafe impl Sync for DocumentCorpus {}
     impl Drop for DocumentCorpus { fn drop(&mut self) { unsafe { ffi::innr_docs_free(self.h) } } }
     impl DocumentCorpus {
+        pub(crate) fn handle(&self) -> *mut ffi::InnrDocs { self.h }
+        /// this shard holds documents [base, base + count) of a range-partitioned corpus (reported indices are global)
+        pub fn set_index_base(&mut self, base: usize) { check(unsafe { ffi::innr_docs_set_index_base(self.h, base as u64) }); }
         /// `tokens`: `[docs][max_tokens][dim]` flattened, `doc_len[i]` valid tokens of document i
         pub fn new(tokens: &[f32], doc_len: Option<&[u32]>, docs: usize, max_tokens: usize, dim: usize) -> Self {
             assert_eq!(tokens.len(), docs * max_tokens * dim);
@@ -507,6 +528,21 @@ pub mod distance {
     impl Distance<u32> for DistSlotU32 {                                                                                         // :128-143
         fn eval(&self, a: &[u32], b: &[u32]) -> f32 { assert_eq!(a.len(), b.len()); unsafe { ffi::innr_slot_distance_u32(a.as_ptr(), b.as_ptr(), a.len()) } }
     }
+
+    /// distance.rs:148-193: with the `anndists` feature the same unit structs also implement `anndists::dist::Distance`, which
+    /// is the trait `hnsw_rs` binds to; one macro line per metric, each delegating to the trait above so the two cannot drift.
+    #[cfg(feature = "anndists")]
+    mod anndists_adapters {
+        use super::{DistCosine, DistDot, DistHamming, DistL1, DistL2, DistSlotU32, Distance};
+        macro_rules! adapt {
+            ($($metric:ty => $elem:ty),* $(,)?) => {$(
+                impl anndists::dist::Distance<$elem> for $metric {
+                    #[inline] fn eval(&self, a: &[$elem], b: &[$elem]) -> f32 { <Self as Distance<$elem>>::eval(self, a, b) }
+                }
+            )*};
+        }
+        adapt!(DistCosine => f32, DistDot => f32, DistL2 => f32, DistL1 => f32, DistHamming => u8, DistSlotU32 => u32);
+    }
 }
 
 /// The sharded path (no counterpart in the reference, which is one process: BASELINE north_star "range-partitioned
@@ -556,6 +592,22 @@ pub mod sharded {
                                       idx.as_mut_ptr(), sc.as_mut_ptr(), &mut got, &mut st)
             });
             (0..nq).map(|q| (0..got).map(|r| (idx[q * got + r] as usize, sc[q * got + r])).collect()).collect()
+        }
+
+        /// global top-k documents of one query over every rank's document shard -- `maxsim` / `maxsim_cosine`
+        /// (maxsim.rs:96-137) of every document of the whole corpus, best first, identical on every rank. Collective.
+        pub fn maxsim(&self, shard: &maxsim::DocumentCorpus, cosine: bool, query_tokens: &[f32], dim: usize, k: usize) -> Vec<(usize, f32)> {
+            assert!(dim > 0 && query_tokens.len() % dim == 0);
+            let tq = query_tokens.len() / dim;
+            let mut idx = vec![0u64; k.max(1)];
+            let mut sc = vec![0f32; k.max(1)];
+            let mut got = 0usize;
+            let mut st = ffi::InnrKnnStats::default();
+            check(unsafe {
+                ffi::innr_sharded_maxsim(self.h, shard.handle(), i32::from(cosine), query_tokens.as_ptr(), tq, dim, k, ffi::INNR_KNN_AUTO,
+                                         idx.as_mut_ptr(), sc.as_mut_ptr(), &mut got, &mut st)
+            });
+            (0..got).map(|r| (idx[r] as usize, sc[r])).collect()
         }
     }
 }

@@ -116,3 +116,98 @@ def test_shard_range_partitions_exactly():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(w - 1))
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _failing_worker(rank, world, port, bad_rank, retq):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from innr_amd import _lib
+    from innr_amd.dist import ShardedKnn, shard_range
+    n_total, dim, nq, k = 90, 8, 4, 5
+    start, count = shard_range(n_total, world, rank)
+    rows = torch.arange(n_total * dim, dtype=torch.float32).reshape(n_total, dim)[start:start + count].sin()
+
+    def local_search(queries, kk):
+        if rank == bad_rank:
+            raise _lib.InnrError(_lib.E_OOM, "hipMalloc for the filter copy failed on this rank only")
+        sc, idx = torch.topk(queries @ rows.T, min(kk, count), dim=1)
+        return idx.to(torch.int64) + start, sc
+
+    sk = ShardedKnn(n_total, local_search=local_search, merge=torch_merge(True))
+    queries = torch.ones((nq, dim))
+    try:
+        sk.search(queries, k)
+        outcome = ("ok", 0, "")
+    except _lib.InnrError as exc:
+        outcome = ("error", exc.status, str(exc))
+    dist.barrier()  # every rank is out of the exchange: nobody is left waiting in the all_gather
+    retq.put((rank, outcome))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, 1), (3, 0)])
+def test_failing_local_search_makes_every_rank_return_an_error(world, bad_rank):
+    """The exchange is symmetric: a rank whose local search fails still gathers (an error block), raises its own error, and
+    every other rank raises INNR_E_RCCL naming it -- nobody hangs in the collective (include/innr_hip.h, innr_sharded_*)."""
+    from innr_amd import _lib
+    ctx = mp.get_context("spawn")
+    retq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, bad_rank, retq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(retq.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, (kind, status, msg) in results.items():
+        assert kind == "error", (rank, kind)
+        if rank == bad_rank:
+            assert status == _lib.E_OOM and "this rank only" in msg
+        else:
+            assert status == _lib.E_RCCL and f"rank {bad_rank}" in msg and f"status {_lib.E_OOM}" in msg
+
+
+def _uid_worker(rank, world, port, retq):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from innr_amd import _lib
+    from innr_amd.dist import Comm
+
+    def no_rccl():
+        raise _lib.InnrError(_lib.E_RCCL, "RCCL is not available: librccl.so[.1] could not be loaded")
+
+    Comm.unique_id = staticmethod(no_rccl)  # what a box without librccl does on rank 0
+    try:
+        Comm.from_torch_group(ctx=None)
+        outcome = "ok"
+    except _lib.InnrError as exc:
+        outcome = f"error {exc.status}: {exc}"
+    # the fallback path of bench.py: every rank must arrive at the SAME next collective
+    ok = torch.tensor([0 if outcome.startswith("error") else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    retq.put((rank, outcome, int(ok.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_bootstrap_failure_on_rank0_reaches_every_rank():
+    """Comm.from_torch_group: rank 0 failing to draw the communicator id must not leave the other ranks in the broadcast
+    (round 2: rank 0 raised first and went on to bench.py's all_reduce while rank 1 still sat in broadcast_object_list)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    retq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uid_worker, args=(r, world, port, retq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [retq.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outcome, agreed in results:
+        assert outcome.startswith("error -5") and "librccl" in outcome and agreed == 0, (rank, outcome)

@@ -12,7 +12,10 @@ import oracle
 
 
 @pytest.mark.parametrize("metric_name,g,n_total,k", [("dot", 4, 40_000, 10), ("cos", 3, 10_001, 33), ("l2", 2, 5_000, 7),
-                                                      ("dot", 8, 20, 5)])
+                                                      ("dot", 8, 20, 5),
+                                                      # 800 candidates per query: the merge kernel's LDS staging at the size the
+                                                      # reference's k = 100 bench gives 8 ranks; 4000: beyond it (global re-reads)
+                                                      ("dot", 8, 30_000, 100), ("l2", 8, 16_000, 500)])
 def test_logical_shards_merge_equals_whole_corpus(metric_name, g, n_total, k):
     import torch
     import innr_amd
@@ -51,6 +54,13 @@ def test_logical_shards_merge_equals_whole_corpus(metric_name, g, n_total, k):
     b_i, b_s = gpu_merge_blocks(ctx, metric, torch.stack(blocks), nq, k)
     torch.cuda.synchronize()
     assert b_i.shape == (nq, kout) and torch.equal(b_i, out_i) and torch.equal(b_s.view(torch.int32), out_s.view(torch.int32))
+    # a rank that failed its local search gathers a block whose header says so (word 1 all ones, word 0 = -status): the merge
+    # then returns an error naming it on every rank instead of a result (include/innr_hip.h, failure semantics)
+    bad = torch.stack(blocks).clone()
+    bad[g - 1, 0], bad[g - 1, 1] = 3, -1
+    with pytest.raises(innr_amd.InnrError) as ei:
+        gpu_merge_blocks(ctx, metric, bad, nq, k)
+    assert ei.value.status == innr_amd._lib.E_RCCL and f"rank {g - 1}" in str(ei.value) and "status -3" in str(ei.value)
     out_i, out_s = out_i.cpu().numpy(), out_s.cpu().numpy()
     data = oracle.from_rows(oracle.generate_uniform(n_total, dim, 7))
     ofn = {"dot": oracle.batch_knn_dot, "cos": oracle.batch_knn_cosine, "l2": oracle.batch_knn}[metric_name]
@@ -175,10 +185,33 @@ def test_rccl_exchange_behind_the_abi_world_1():
         oi, os_ = oracle.batch_knn_u8(queries[j], codes, oracle.QParams(p.alpha, p.offset), k)
         assert idx[j].cpu().numpy().tolist() == oi.astype(np.int64).tolist()
         assert np.array_equal(sc[j].cpu().numpy().view(np.uint32), os_.view(np.uint32))
-    # a dimension mismatch is reported like the local call's (before anything is exchanged)
+    # a dimension mismatch is reported like the local call's (the rank still gathers: an error block)
     with pytest.raises(innr_amd.InnrPanic):
         sk.search(torch.zeros((2, dim + 1), device=dev), k)
+    # a rank-local failure of the local search (here on request): this rank returns its own status -- after taking part in the
+    # exchange -- and the communicator stays usable
+    with ctx.option("fail_local_search", 1):
+        with pytest.raises(innr_amd.InnrError) as ei:
+            sk.search(q_dev, k)
+        assert ei.value.status == innr_amd._lib.E_HIP and "on request" in str(ei.value)
+    idx2, sc2 = sk.search(q_dev, k)
+    assert torch.equal(idx2, idx) and torch.equal(sc2.view(torch.int32), sc.view(torch.int32))
+    # maxsim through the same exchange (innr_sharded_maxsim): a document shard, one query
+    from innr_amd import maxsim as M
+    ndocs, T, mdim, Tq, mk = 5000, 32, 64, 8, 15
+    dc = M.DocumentCorpus.generate(ndocs, T, mdim, seed=9, ctx=ctx)
+    rq = oracle.generate_uniform(Tq, mdim, 77)
+    mq = (rq / np.sqrt((rq.astype(np.float64) ** 2).sum(axis=1, keepdims=True))).astype(np.float32)
+    for cosine in (False, True):
+        want_i, want_s = dc.topk(mq, mk, cosine=cosine, engine=innr_amd.KNN_EXACT)
+        skd = ShardedKnn(ndocs, rank=0, world=1, comm=comm)
+        skd.attach_gpu_docs(dc, cosine=cosine)
+        mi, ms = skd.search(torch.from_numpy(mq).to(dev), mk)
+        assert mi.shape == (1, mk) and mi[0].cpu().numpy().tolist() == want_i.astype(np.int64).tolist()
+        assert np.array_equal(ms[0].cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+    mi, ms = skd.search(torch.from_numpy(mq).to(dev), ndocs + 7)  # k beyond the corpus: k' = ndocs
+    assert mi.shape == (1, ndocs)
     comm.close()
-    for o in (vb, small, qc):
+    for o in (vb, small, qc, dc):
         o.close()
     ctx.close()

@@ -262,6 +262,18 @@ def test_device_quantize_and_fit_match_host(S, innr):
     empty = B.VerticalBatch.from_rows(np.empty((0, 0), np.float32))
     e = S.fit_batch(empty)
     assert (e.alpha, e.offset) == (1.0, 0.0)
+    # degenerate corpora: `fit` scans from (f32::MAX, f32::MIN) and has no min > max guard (scalar.rs:68-87) -- a non-empty
+    # all-NaN corpus gives {1.0, f32::MAX}; values beyond +-f32::MAX (the infinities) never replace the starting values
+    for vals in (np.full((4, 3), np.nan, np.float32), np.full((2, 5), np.inf, np.float32), np.full((3, 2), -np.inf, np.float32),
+                 np.array([[np.nan, np.inf], [-np.inf, np.nan]], np.float32), np.array([[np.nan, 2.0], [np.nan, np.nan]], np.float32)):
+        dv = B.VerticalBatch.from_rows(vals)
+        got, want, host = S.fit_batch(dv), oracle.qparams_fit(vals.reshape(-1)), S.QuantizationParams.fit(vals.reshape(-1))
+        for x in (got, host):
+            assert np.float32(x.alpha).view(np.uint32) == np.float32(want.alpha).view(np.uint32), (vals, x, want)
+            assert np.float32(x.offset).view(np.uint32) == np.float32(want.offset).view(np.uint32), (vals, x, want)
+        dv.close()
+    nanp = S.fit_batch(B.VerticalBatch.from_rows(np.full((4, 3), np.nan, np.float32)))
+    assert (nanp.alpha, np.float32(nanp.offset)) == (1.0, np.float32(3.4028235e38))
 
 
 @pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
@@ -366,10 +378,10 @@ def test_rerank_and_ingest_edge_cases(S, innr):
     with pytest.raises(innr.InnrError):
         B.batch_rerank(q[:1], vb, np.array([[7]], np.uint64), 1)  # below the base
     vb.set_index_base(0)
-    # quantising an all-NaN / constant corpus: fit falls back to (1, 0) / alpha 1 (scalar.rs:57)
+    # quantising an all-NaN / constant corpus: fit gives alpha 1 (scalar.rs:57); NaN quantises to 0 (`as u8`)
     nanb = B.VerticalBatch.from_rows(np.full((4, 3), np.nan, np.float32))
     p = S.fit_batch(nanb)
-    assert (p.alpha, p.offset) == (1.0, 0.0)
+    assert (p.alpha, np.float32(p.offset)) == (1.0, np.float32(3.4028235e38))  # scalar.rs:68-87 has no min > max guard
     assert np.all(S.QuantizedCorpus.from_batch(nanb, p).codes() == 0)
     const = B.VerticalBatch.from_rows(np.full((4, 3), 2.5, np.float32))
     p = S.fit_batch(const)

@@ -86,6 +86,8 @@ struct innr_tuning {
     long maxsim_generic = 0;     // maxsim MFMA engine: the generic kernel instead of the tile-unrolled one
     long no_k_rule = 0;          // chip-wide bounds by the KP rule only (topk_dev.h): A/B of the k rule
     long fail_local_search = 0;  // TEST switch of the sharded calls: this rank's local search reports a failure
+    long no_completion = 0;      // unproven queries of the f32 engine: straight to the KP retry / exact engine (no completion pass)
+    long trace = 0;              // diagnostics of the redo paths on stderr (list lengths of the completion pass, ...)
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -95,7 +97,7 @@ static const TuneName kTuneNames[] = {
     {"i8_two_limb", &innr_tuning::i8_two_limb}, {"no_auto_bf16", &innr_tuning::no_auto_bf16},
     {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
-    {"fail_local_search", &innr_tuning::fail_local_search},
+    {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -155,6 +157,7 @@ struct innr_ctx {
     struct RedoBufs {
         DevBuf q, idx, sc, map, qn;
     } redo[2];  // unproven queries, gathered and redone as ONE batch; [1]: the batch's own unproven queries (redo_batch)
+    RedoBufs cmpl;     // the completion pass of unproven queries (knn_complete)
     DevBuf q_hat;      // int8 filter of an f32 corpus, cosine: the normalised queries
     DevBuf q_pad;      // exact engine: a ragged tail of 2-3 / 5-7 queries padded with zero rows to a 4- / 8-query pass
     DevBuf q_one;      // full-sort path (k > INNR_MAX_K): one zero-padded query row
@@ -622,7 +625,7 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, size_t nreal_q,
     uint32_t* gslots = nullptr;
     size_t nslot = 0;
     if (!kmargin) kk = 0;
-    INNR_TRY(prep_gthr(c, p.Qpad, p.KP, seed, nreal_q, kmargin, &gslots, &nslot));
+    INNR_TRY(prep_gthr(c, p.Qpad, MODE == 2 ? 32u : p.KP, seed, nreal_q, kmargin, &gslots, &nslot));  // (MODE 2: only the bounds are used)
 #define INNR_GEMM_LAUNCH_W(RR, WV)                                                                               \
     gemm_filter_kernel<KIND, RR, MODE, WV><<<p.nblocks, 64 * WV, 0, c->stream>>>(                                  \
         KIND == kGemmU8 ? (const void*)b->C8 : (const void*)b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->Dpad, Qt, p.Qpad, \
@@ -637,6 +640,10 @@ static innr_status launch_gemm(innr_batch* b, const GemmPlan& p, size_t nreal_q,
         else if (MODE == 0 && KIND != kGemmU8 && p.waves == 1) INNR_GEMM_LAUNCH_W(RR, ((MODE == 0 && KIND != kGemmU8) ? 1 : 4)); \
         else INNR_GEMM_LAUNCH_W(RR, 4);                                                                         \
     } while (0)
+    if constexpr (MODE == 2) {  // collect (knn_complete): the list geometry plays no part; 8-wave tiles for the dot kind only
+        if (KIND == kGemmDot && p.waves == 8) INNR_GEMM_LAUNCH_W(6, ((MODE == 2 && KIND == kGemmDot) ? 8 : 4));
+        else INNR_GEMM_LAUNCH_W(6, 4);
+    } else
     switch (p.cap) {
         case 384: INNR_GEMM_LAUNCH(6); break;
         case 512: INNR_GEMM_LAUNCH(8); break;
@@ -758,6 +765,172 @@ static innr_status redo_batch(innr_batch* b, int metric, const float* dQ, const 
     scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(
         rb.idx.as<uint64_t>(), rb.sc.as<float>(), map, (uint32_t)nr, (uint32_t)kout, d_out_idx, d_out_score);
     INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+
+// ---- completion pass for queries whose margin proof failed (f32 GEMM engine) ------------------------------------------------
+// After the first pass an unproven query has k candidates with EXACT scores; the k-th of them, x_k, is a lower bound of the
+// corpus' true k-th best score, and every member v of the true top k has exact(v) >= x_k, hence approx(v) >= x_k - E. ONE more
+// GEMM pass over the unproven queries with that FIXED threshold collects every such site into a global list per query (MODE 2 of
+// gemm_filter_kernel: no list capacity to run against, no bound that moves); all collected candidates are re-scored in the
+// reference's order and the best k of them ARE the answer -- proven, whatever the gaps between neighbouring scores. Near-tie
+// data (the reference example's LCG rows: hundreds of vectors within 2E of every k-th score) used to send every query through
+// the exact engine, 8 per corpus pass: 1024 queries = 128 passes = 0.84 s at C2; the completion pass is one GEMM pass (~0.11 s)
+// plus a few hundred exact dots per query. Queries whose list overflows kCollectCap (or whose x_k / E is not finite) stay
+// unresolved and take the exact engine as before.
+constexpr uint32_t kCollectCap = kSelSlots;  // 4096 candidates per query: one LDS sort window (kernels_topk.h)
+
+__global__ void gather_kth_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ map, uint32_t n, uint32_t k,
+                                  float* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = scores[(size_t)map[t] * k + (k - 1)];
+}
+
+// exact score of every collected candidate, in the reference's order (cf. rerank_scores_kernel): one thread per (query, slot)
+template <int MET>
+__global__ __launch_bounds__(256) void collect_scores_kernel(const float* __restrict__ V, size_t ldN, uint32_t D, const float* __restrict__ Qm,
+                                                              const float* __restrict__ norms, const float* __restrict__ qnorm,
+                                                              const uint32_t* __restrict__ clist, const uint32_t* __restrict__ ccnt,
+                                                              uint32_t cap, uint64_t* __restrict__ keys) {
+    constexpr bool COS = MET == 1, L2 = MET == 2;
+    const uint32_t q = blockIdx.y;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = ccnt[q] < cap ? ccnt[q] : cap;
+    if (slot >= n) return;  // (the selection reads only the first n keys)
+    const uint32_t i = clist[(size_t)q * cap + slot];
+    const float* qv = Qm + (size_t)q * D;
+    const float* col = V + i;
+    float acc = 0.0f;
+    if (L2) {
+#pragma unroll 8
+        for (uint32_t d = 0; d < D; ++d) {
+            const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
+            acc = ex::mad2(acc, diff, diff);
+        }
+    } else {
+#pragma unroll 8
+        for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
+    }
+    if (COS) {
+        const float qn = qnorm[q], vn = norms[i];
+        acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
+    }
+    keys[(size_t)q * cap + slot] = cand_make(score_pref<L2>(acc), i);
+}
+
+// best kout of a query's n <= kSelSlots exact composites: one workgroup per query, one LDS bitonic sort
+__global__ __launch_bounds__(kSelThreads) void segment_topk_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ccnt,
+                                                                    uint32_t cap, uint32_t kout, bool smaller_is_better,
+                                                                    uint64_t index_base, uint64_t* __restrict__ out_idx,
+                                                                    float* __restrict__ out_score, uint32_t* __restrict__ unresolved) {
+    __shared__ uint64_t s[kSelSlots];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = ccnt[q];
+    if (n > cap || n < kout) {  // overflow (or a threshold that was not a bound: non-finite scores): the exact engine decides
+        if (threadIdx.x == 0) unresolved[q] = 1u;
+        return;
+    }
+    const int np = next_pow2_i((int)n > 1 ? (int)n : 1);
+    for (int e = threadIdx.x; e < np; e += kSelThreads) s[e] = (uint32_t)e < n ? keys[(size_t)q * cap + e] : 0ull;
+    __syncthreads();
+    wg_bitonic_desc(s, np);
+    for (uint32_t r = threadIdx.x; r < kout; r += kSelThreads) {
+        out_idx[(size_t)q * kout + r] = index_base + cand_idx(s[r]);
+        out_score[(size_t)q * kout + r] = pref_score(cand_pref(s[r]), smaller_is_better);
+    }
+}
+
+// redo: the unproven queries (ascending), d_out_*: the first pass' output (its k-th score per query is read, the resolved
+// queries' rows are overwritten). *unresolved: those that still need the exact engine.
+static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, const std::vector<uint32_t>& redo, size_t kout,
+                                uint64_t* d_out_idx, float* d_out_score, std::vector<uint32_t>* unresolved, float* gemm_ms) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size(), D = b->D;
+    unresolved->clear();
+    if (nr == 0) return INNR_OK;
+    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
+    innr_ctx::RedoBufs& rb = c->cmpl;  // its own set: a nested pass (redo_batch -> knn_mfma) runs while redo[level] is live
+    INNR_TRY(rb.map.ensure(nr * sizeof(uint32_t)));
+    INNR_TRY(rb.q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
+    INNR_TRY(rb.qn.ensure(nr * sizeof(float)));
+    INNR_TRY(rb.idx.ensure(nr * kout * sizeof(uint64_t)));
+    INNR_TRY(rb.sc.ensure(nr * kout * sizeof(float)));
+    INNR_HIP_CHECK(hipMemcpyAsync(rb.map.p, redo.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    INNR_HIP_CHECK(hipStreamSynchronize(c->stream));  // redo is a pageable host vector
+    const uint32_t* map = rb.map.as<uint32_t>();
+    gather_rows_kernel<<<(unsigned)((nr * D + 255) / 256), 256, 0, c->stream>>>(dQ, map, (uint32_t)nr, (uint32_t)D, rb.q.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    gather_kth_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>(d_out_score, map, (uint32_t)nr, (uint32_t)kout, rb.qn.as<float>());
+    INNR_HIP_CHECK(hipGetLastError());
+    const float* kth = rb.qn.as<float>();  // x_k per unproven query
+    const float* Qr = rb.q.as<float>();
+    GemmPlan p = plan_gemm(b, nr, kout, (!cos && !l2 && nr > 256) ? 8u : 4u, !cos && !l2);
+    p.KP = 32;  // (the slots of prep_gthr are not used in collect mode)
+    if (cos) INNR_TRY(ensure_invnorms(b));
+    if (l2) INNR_TRY(ensure_sqnorms(b));
+    INNR_TRY(prep_queries(b, p, Qr, nr, cos));  // K-major queries, exact norms (c->q_norm), cosine: 1/|q| at c->misc
+    float* invq = c->misc.as<float>();
+    float* Cj = nullptr;
+    if (l2) {
+        INNR_TRY(c->tmp_norms.ensure(p.Qpad * sizeof(float)));
+        Cj = c->tmp_norms.as<float>();
+        l2_query_consts_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, nr, b->max_norm, invq, Cj);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
+    const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;  // the f32 engine's bounds (knn_mfma)
+    const float err_scale = l2 ? 1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f : (cos ? cdu : cdu * b->max_norm);
+    // fixed thresholds: x_k - E (one key lower), in the kind's score space; 0 = "no bound" where that is not finite
+    INNR_TRY(c->seed_score.ensure(p.Qpad * sizeof(uint32_t)));
+    uint32_t* thr = c->seed_score.as<uint32_t>();
+    seed_thresholds_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(kth, (uint32_t)nr, 1u, l2 ? 2 : (cos ? 1 : 0), err_scale,
+                                                                                    c->q_norm.as<float>(), Cj, thr, (uint32_t)p.Qpad, 0u);
+    INNR_HIP_CHECK(hipGetLastError());
+    // global lists: [Qpad][kCollectCap] indices, [Qpad] lengths
+    INNR_TRY(c->lists.ensure(p.Qpad * (size_t)kCollectCap * sizeof(uint32_t)));
+    INNR_TRY(c->counts.ensure(p.Qpad * sizeof(uint32_t)));
+    INNR_HIP_CHECK(hipMemsetAsync(c->counts.p, 0, p.Qpad * sizeof(uint32_t), c->stream));
+    GemmPlan pl = p;
+    pl.KP = kCollectCap;  // what the kernel takes as the list capacity (launch_gemm sizes the unused slots for MODE 2 by itself)
+    INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    if (cos) INNR_TRY((launch_gemm<kGemmCos, 2>(b, pl, nr, c->q_kmajor.as<float>(), b->invn, invq, nullptr, 0, thr)));
+    else if (l2) INNR_TRY((launch_gemm<kGemmL2, 2>(b, pl, nr, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, thr)));
+    else INNR_TRY((launch_gemm<kGemmDot, 2>(b, pl, nr, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, thr)));
+    INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    // exact scores of everything collected, best k per query
+    INNR_TRY(c->sort_keys.ensure(nr * (size_t)kCollectCap * sizeof(uint64_t)));
+    uint64_t* keys = c->sort_keys.as<uint64_t>();
+    const uint32_t* clist = c->lists.as<uint32_t>();
+    const uint32_t* ccnt = c->counts.as<uint32_t>();
+    const dim3 sg(kCollectCap / 256, (unsigned)nr);
+    if (cos) collect_scores_kernel<1><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    else if (l2) collect_scores_kernel<2><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    else collect_scores_kernel<0><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_TRY(c->sel_cnt.ensure(nr * sizeof(uint32_t)));
+    uint32_t* unres = c->sel_cnt.as<uint32_t>();
+    INNR_HIP_CHECK(hipMemsetAsync(unres, 0, nr * sizeof(uint32_t), c->stream));
+    segment_topk_kernel<<<(unsigned)nr, kSelThreads, 0, c->stream>>>(keys, ccnt, kCollectCap, (uint32_t)kout, l2, b->index_base,
+                                                                    rb.idx.as<uint64_t>(), rb.sc.as<float>(), unres);
+    INNR_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> un(nr);
+    INNR_HIP_CHECK(copy_out(c, un.data(), unres, nr * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
+    float ms = 0.0f;
+    if (gemm_ms && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms += ms;
+    // resolved rows back to their places (the unresolved ones are rewritten by the exact engine afterwards)
+    scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(rb.idx.as<uint64_t>(), rb.sc.as<float>(), map, (uint32_t)nr,
+                                                                                   (uint32_t)kout, d_out_idx, d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
+    for (size_t r = 0; r < nr; ++r)
+        if (un[r]) unresolved->push_back(redo[r]);
+    if (c->tune.trace) {
+        std::vector<uint32_t> cnt(nr);
+        INNR_HIP_CHECK(hipMemcpyAsync(cnt.data(), ccnt, nr * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::sort(cnt.begin(), cnt.end());
+        fprintf(stderr, "knn_complete: %zu queries, collected per query min %u / median %u / max %u (capacity %u), %zu unresolved\n", nr,
+                cnt.front(), cnt[nr / 2], cnt.back(), kCollectCap, unresolved->size());
+    }
     return INNR_OK;
 }
 
@@ -965,6 +1138,19 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
         if (fb[q]) redo.push_back((uint32_t)q);  // margin proof failed (near-tie at the cut, or non-finite scores)
     *nfallback = (uint32_t)redo.size();
     *kept = p.KP;
+    // f32 engine: ONE completion pass resolves what the first pass could not prove (knn_complete); a handful of queries is
+    // cheaper on the exact engine (one 8-query corpus pass costs less than a GEMM pass over a 256-query tile)
+    bool completed = false;
+    if (!use_bf16 && redo.size() > 8 && !c->tune.no_completion && (b->max_norm - b->max_norm == 0.0f)) {
+        completed = true;
+        std::vector<uint32_t> still;
+        INNR_TRY(knn_complete(b, metric, dQ, redo, kout, d_out_idx, d_out_score, &still, gemm_ms));
+        redo.swap(still);
+        if (cos || !redo.empty()) {  // (the completion pass used the query workspace: the redo below reads the norms again)
+            query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+            INNR_HIP_CHECK(hipGetLastError());
+        }
+    }
     if (!redo.empty()) {
         const float* qn_all = cos ? c->q_norm.as<float>() : nullptr;
         uint32_t via = 0;
@@ -972,7 +1158,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
             // The bf16 bound is ~2^15 times the f32 one: on data with small gaps at the cut many proofs fail. Those
             // queries go through the f32 GEMM engine as one batch (its own proof, and the exact engine behind it).
             via = pick_kp(kout, 16);
-        } else if (!use_bf16 && !kp_force && p.KP < 256 && redo.size() >= 16 && redo.size() * 4 <= Q &&
+        } else if (!use_bf16 && !completed && !kp_force && p.KP < 256 && redo.size() >= 16 && redo.size() * 4 <= Q &&
                    !c->tune.gemm_no_kp_retry) {
             // A minority of the batch failed: isolated clusters of near-equal scores (duplicates, quantised data), which
             // lists of 256 candidates usually swallow -- one more GEMM pass over those queries instead of an exact scan
@@ -1078,7 +1264,8 @@ void innr_ctx_destroy(innr_ctx* c) {
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad, &c->q_hat,
                       &c->redo[0].q, &c->redo[0].idx, &c->redo[0].sc, &c->redo[0].map, &c->redo[0].qn,
-                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn, &c->kmargin};
+                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn, &c->kmargin,
+                      &c->cmpl.q, &c->cmpl.idx, &c->cmpl.sc, &c->cmpl.map, &c->cmpl.qn};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     for (auto& ev : c->ev)

@@ -141,6 +141,10 @@ enum { kGemmDot = 0, kGemmCos = 1, kGemmU8 = 2, kGemmL2 = 3 };
 //                ds_read_b32 feeds the four row tiles) and score = scale * (q.c) + invq[j]   (invq = offset*sum(q)):
 //                "path B" of SURVEY.md -- the f32 MFMA pipe, a quarter of the corpus bytes.
 // MODE 0: fused top-k filter (product path).  MODE 1: dump the dense score matrix (layout test only).
+// MODE 2: COLLECT -- the completion pass of queries whose proof failed (knn_complete, api.hip): every query has a FIXED
+//   threshold (gthr[q], set by the host: its k-th exact score so far, less E), and every site whose approximate score clears
+//   it is appended to the query's GLOBAL list (`lists` = uint32 indices [Qpad][KP], `counts` = uint32 [Qpad] list lengths, KP =
+//   the capacity; an overfull list keeps counting, the host sees the overflow). No slots, no compaction, no bound moves.
 // WAVES: 8 = 512-query tile, one block per CU; 4 = 256 queries, two blocks per CU; 2 / 1 = 128 / 64 queries for small query
 // batches (a 64-query batch on a 256-query tile spends three quarters of its MFMAs on padding: 27 ms instead of ~8 at C2),
 // several blocks per CU, each streaming its own corpus slice (not for the u8 kind, whose small batches take the int8 engine).
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 1 : 2) void gemm_filter_ke
     // chip-wide thresholds of this lane's two queries: read here (they may be seeded, see seed_thresholds_kernel) and
     // refreshed at the end of every tile's epilogue
     uint32_t tg_next[2] = {0u, 0u};
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + ct, 8u * (uint32_t)(lane & 31));
     }
@@ -567,7 +571,12 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
                 out_score[(size_t)q * kout + rank[r]] = pref_score(cand_pref(e[r]), L2);
             }
         }
-        if (failed && lane == 0) fallback[q] = 1;
+        if (failed && lane == 0) {
+            fallback[q] = 1;
+            // the completion pass (knn_complete) reads the k-th score of a failed query as a lower bound of the true one:
+            // with fewer than k candidates there is none
+            if (done < kout) out_score[(size_t)q * kout + kout - 1] = __builtin_nanf("");
+        }
         return;
     }
 }

@@ -555,16 +555,31 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 #endif
 // Timing probes of the one-limb kernel are COMPILE-TIME switches (builds with -DINNR_I8H_PROBE=<bits>, tools/i8h_probe.py;
 // the product library is built without them: no probe branch exists in its K-loop). Bits -- 1: the epilogue never visits (what the
-// K-loop and the fast reject cost); 8 / 16: the query fragments of every K-step come from step 0 (L1) / every DMA re-reads the
-// slice's first stage (L2); 32: no epilogue at all; 4: count visiting wave epilogues / survivors / bound re-derivations and the
-// cycles they take into errflag[8..17]. Builds with bits 1, 8, 16 or 32 give wrong answers and their calls fail after filling the stats.
+// K-loop and the fast reject cost; the hits are counted so that the reject is not dead code); 8 / 16: the query fragments of every
+// K-step come from step 0 (L1) / every DMA re-reads the slice's first stage (L2); 32: no fast reject either (the accumulators are
+// folded into one word per lane: a probe build whose accumulators nobody reads loses its MFMAs to dead-code elimination -- the
+// first compile-time version of bits 1 and 32 "measured" a 4.1 ms K-loop that multiplied nothing); 4: count visiting wave
+// epilogues / survivors / bound re-derivations and the cycles they take into errflag[8..17]. Builds with bits 1, 8, 16 or 32 give
+// wrong answers and their calls fail after filling the stats.
 #ifndef INNR_I8H_PROBE
 #define INNR_I8H_PROBE 0
 #endif
 constexpr uint32_t kI8hProbe = INNR_I8H_PROBE;
 constexpr int kI8hBQ = 512, kI8hS = INNR_I8H_S;
 
-constexpr int kI8hSurvCap = 128;  // survivors a wave queues before it finishes them (at least one round: 64)
+constexpr int kI8hSurvCap = 128;  // survivors a wave queues before it must finish them (at least one site's worth: 64)
+// The queued survivors are finished every kI8hFlushEvery-th tile of a slice (every wave of the block at the same tile), or as soon as
+// a wave's list holds kI8hFlushAt of them. C2 shape, kernel ms (tools/i8_ab.py over builds with -DINNR_I8H_FLUSH_EVERY=1 / 2 / 4 / 8 /
+// 16 / 64): 8.29 / 8.14 / 8.13 / 8.15 / 8.45 / 8.77 -- a survivor that waits keeps its slot from raising the chip-wide bound, and
+// past a few tiles that costs more survivors than the rarer visits save (profiles/r03_i8_flush_ab.txt).
+#ifndef INNR_I8H_FLUSH_EVERY
+#define INNR_I8H_FLUSH_EVERY 4
+#endif
+#ifndef INNR_I8H_FLUSH_AT
+#define INNR_I8H_FLUSH_AT 48
+#endif
+constexpr int kI8hFlushEvery = INNR_I8H_FLUSH_EVERY, kI8hFlushAt = INNR_I8H_FLUSH_AT;
+static_assert(kI8hFlushAt + 64 <= kI8hSurvCap + 64 && kI8hFlushEvery >= 1, "list geometry");
 struct alignas(16) GemmI8hLds {
     alignas(16) char A[kI8Stages * kI8StageBytes];
     uint32_t cnt[kI8hBQ];
@@ -691,6 +706,10 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     }
     uint32_t tile = t0, ks = 0;
     // probe bit 4 (tools/i8h_probe.py): per wave, flushed once at the end -- per-event atomics on one address slowed the kernel 5x
+#ifdef INNR_I8H_SETPRIO  // A/B switch (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the block's younger half
+    if (wu >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    uint32_t ns = 0;  // survivors queued in this wave's LDS list (wave-uniform; carried from tile to tile)
     uint32_t pc_nvis = 0, pc_nsurv = 0, pc_npub = 0;
     unsigned long long pc_visit = 0, pc_surv = 0, pc_tail = 0;  // cycles inside visits / inside the survivors' loops / publish + compaction
     for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
@@ -745,8 +764,16 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                 dump[q * ld_dump + i] = __builtin_fmaf(Aj[ct], (float)V, Bj[ct]);
                             }
                     }
-                } else if (kI8hProbe & 32) {  // timing only: no epilogue at all (the bare K-loop)
+                } else if (kI8hProbe & 32) {  // timing only: no fast reject -- the accumulators are only folded into one word per lane, so that no MFMA is dead code
                     use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
+                    int32_t fold = 0;
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) fold ^= acc[rt][ct][g];
+                    pc_nsurv += (uint32_t)fold;
                 } else {
                     use_after<kEpiTgWait>(tg_next[0], tg_next[1]);
                     uint32_t thr[2];
@@ -794,32 +821,28 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         hit[ct] = (b01 > b23 ? b01 : b23) >= Thi[ct];
                     }
                     constexpr bool probe = (kI8hProbe & 4) != 0;
-                    if (__any(hit[0] || hit[1]) && !(kI8hProbe & 1)) {
-                        const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
-                        pc_nvis += probe ? 1u : 0u;
-                        // A visit borrows the K-loop's operand ring: once everything the wave has in flight has landed (the wait
-                        // a survivor's first load would sit out anyway), the ring's 32 registers hold nothing a visit needs -- its
-                        // fragments are requested again at the end -- and give the survivors' loads room to go out four
-                        // survivors at a time. (With registers of their own those loads pushed the ring into scratch, and
-                        // tools/check_gemm_asm.py refused the build.)
-#pragma unroll
-                        for (int r = 0; r < kI8Lead; ++r) {
-                            use_after<0>(breg[r][0], breg[r][1]);
-                            use_after<0>(breg[r][2], breg[r][3]);
-                        }
-                        asm volatile("; innr operand ring released" ::: "memory");
-                        // Phase 1: every lane queues its surviving sites (high limb, corpus row, lane and query column) in the wave's
-                        // LDS list -- in rounds: round r takes each lane's r-th survivor of a group of 16 sites (static register
-                        // indices, one compare + select per site), all lanes of a round write at once.
-                        // Phase 2 (flush): the queued survivors are finished FOUR per memory round trip. A survivor needs lo = the
-                        // dot of its corpus row with its query's low limb (nk * 4 chunks of 16 dimensions: a 16-byte load of
-                        // each, four v_dot4_i32_i8); quarter g of the wave computes the one of entry g, each of its 16 lanes
-                        // every 16th chunk with all its loads requested before the first is used, then a 4-step reduction; the
-                        // lane that owns the query runs the exact test and the append. One at a time a survivor cost 1 800
-                        // cycles, its own L2 round trip, and a visit has 6.5 of them, scattered over groups and rounds
-                        // (tools/i8h_probe.py) -- hence the list.
-                        uint32_t ns = 0;
+                    // ---- survivors: QUEUED per tile, FINISHED per kI8hFlushEvery tiles, by all waves of the block at once ----
+                    // Finishing a survivor needs memory (its corpus row and its query's low limb): a wave that does it waits for
+                    // everything it has in flight and holds its block at the next barrier meanwhile -- measured (compile-time
+                    // probes, C2): K-loop + fast reject 4.2 ms, with a visit in every wave epilogue that has a survivor 8.5 ms
+                    // (380 K visits of 9.7 K cycles, two or three per block tile, each stalling eight waves). So a tile's
+                    // epilogue only QUEUES its survivors in the wave's LDS list (no vector memory instruction, the operand
+                    // ring stays in flight), and the lists are finished in a VISIT that every wave of the block makes at the
+                    // same tile: every kI8hFlushEvery-th tile of the slice and its last one -- the block stalls once for all
+                    // eight -- or earlier when a wave's list runs full (early tiles, weak bounds). A queued survivor reaches
+                    // the candidate lists and the chip-wide bound a few tiles late: the bound only lags, nothing is lost (the
+                    // exact test at the visit uses the thresholds of that moment).
+                    // (probe bit 1: the hits are only counted -- the count keeps the fast reject, and with it every MFMA, alive in that build)
+                    if ((kI8hProbe & 1) && __any(hit[0] || hit[1])) ++pc_nvis;
+                    const bool any_hit = __any(hit[0] || hit[1]) && !(kI8hProbe & 1);
+                    const bool sync_flush = (tile + 1 == t1) || ((tile - t0) % (uint32_t)kI8hFlushEvery == (uint32_t)kI8hFlushEvery - 1u);
+                    if (any_hit || (sync_flush && ns)) {
                         bool admitted[2] = {false, false};
+                        // Finish the queued survivors FOUR per memory round trip. A survivor needs lo = the dot of its corpus
+                        // row with its query's low limb (nk * 4 chunks of 16 dimensions: a 16-byte load of each, four
+                        // v_dot4_i32_i8); quarter g of the wave computes the one of entry g, each of its 16 lanes every 16th
+                        // chunk with all its loads requested before the first is used, then a 4-step reduction; the lane that
+                        // owns the query runs the exact test and the append.
                         auto flush = [&]() {
                             __builtin_amdgcn_wave_barrier();
                             const unsigned long long ps0 = probe ? __builtin_readcyclecounter() : 0ull;
@@ -828,8 +851,8 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                 const uint32_t nb = ns - e0 < 4u ? ns - e0 : 4u;
                                 const uint32_t em = e0 + ((uint32_t)g_mine < nb ? (uint32_t)g_mine : 0u);
                                 const uint32_t hi_m = s.surv[wu][em][0], row_m = s.surv[wu][em][1], lc_m = s.surv[wu][em][2];
-                                const uint32_t rr = row_m - (uint32_t)tb;  // row inside the tile: 4 i_ + rt
-                                const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)tile * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
+                                const uint32_t rr = row_m & 127u;  // row inside its tile: 4 i_ + rt
+                                const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)(row_m >> 7) * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
                                 const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (q0 + 64 * wu + 32 * ((lc_m >> 8) & 1u) + (lc_m & 31u));
                                 int32_t part = 0;
                                 for (uint32_t c0 = 0; c0 < nk * 4; c0 += 48) {  // 48 chunks (768 dimensions) per pass: three per lane
@@ -876,97 +899,170 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                             __builtin_amdgcn_wave_barrier();
                             if (probe) pc_surv += __builtin_readcyclecounter() - ps0;
                         };
+                        // A visit borrows the K-loop's operand ring: once everything the wave has in flight has landed (the wait
+                        // a survivor's first load would sit out anyway), the ring's 32 registers hold nothing a visit needs -- its
+                        // fragments are requested again at the end -- and give the survivors' loads room to go out four
+                        // survivors at a time. (With registers of their own those loads pushed the ring into scratch, and
+                        // tools/check_gemm_asm.py refused the build.)
+                        auto ring_release = [&]() {
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
+                            for (int r = 0; r < kI8Lead; ++r) {
+                                use_after<0>(breg[r][0], breg[r][1]);
+                                use_after<0>(breg[r][2], breg[r][3]);
+                            }
+                            asm volatile("; innr operand ring released" ::: "memory");
+                        };
+                        // finish what is queued, re-derive the chip-wide bounds that asked for it, compact lists that run short of room
+                        auto finish = [&]() {
+                            flush();
+                            unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
+                            pc_npub += probe ? (uint32_t)(__popcll(admitted_by[0]) + __popcll(admitted_by[1])) : 0u;
+                            const unsigned long long pt1 = probe ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
-                                if (!__any(ghit)) continue;  // wave-uniform: most visits touch one group of one query column
-                                int taken = 0;
-                                while (true) {
-                                    int32_t sel_hi = 0;
-                                    int sel_site = -1, seen = 0;
+                            for (int ct = 0; ct < 2; ++ct) {
+                                unsigned long long m = admitted_by[ct];
+                                m = (m | (m >> 32)) & 0xffffffffull;
+                                while (m) {
+                                    const int L = __builtin_ctzll(m);
+                                    m &= m - 1;
+                                    const size_t qg = q0 + 64 * wu + 32 * ct + L;  // wave-uniform
+                                    gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane, kk, kmargin[qg]);
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            unsigned long long need = __ballot(c > cap - kGemmBurst);
+                            while (need) {
+                                const int j = __builtin_ctzll(need);
+                                need &= need - 1;
+                                const int qj = 64 * w + j;
+                                const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                                uint32_t t;
+                                const uint32_t keep = wave_compact<R>(my_lists + (size_t)qj * cap, cj, KP, &t);
+                                if (lane == 0) {
+                                    s.cnt[qj] = keep;
+                                    s.thr[qj] = t;
+                                    if (t > __hip_atomic_load(&gthr[q0 + qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                        __hip_atomic_fetch_max(&gthr[q0 + qj], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            if (probe) pc_tail += __builtin_readcyclecounter() - pt1;
+                        };
+                        // give the ring back: the fragments of the next two K-steps again (ring slot r holds K-step b_ks - 2 + r),
+                        // and nothing may be in flight when the K-loop's counted waits resume
+                        auto ring_reclaim = [&]() {
+                            asm volatile("; innr operand ring reclaimed" ::: "memory");
+#pragma unroll
+                            for (int r = 0; r < kI8Lead; ++r) {
+                                const uint32_t kidx = (b_ks + 2u * nk - (uint32_t)kI8Lead + (uint32_t)r) % nk;
+                                issue_b_at(breg[r][0], breg[r][1], 0, kidx);
+                                issue_b_at(breg[r][2], breg[r][3], 1, kidx);
+                            }
+                            wait_all();
+#pragma unroll
+                            for (int r = 0; r < kI8Lead; ++r) {
+                                use_after<0>(breg[r][0], breg[r][1]);
+                                use_after<0>(breg[r][2], breg[r][3]);
+                            }
+                        };
+                        // How many survivors does this tile bring? Usually a handful per wave; a launch without seeded bounds (a small
+                        // corpus) passes every site of its first tiles. A tile that fits is queued as it stands; one that does not
+                        // is walked in ROUNDS with the list emptied in between (round r takes each lane's r-th survivor of a group
+                        // of 16 sites: at most one entry per lane and round) -- which needs the visit's registers, so the visit
+                        // starts before the walk.
+                        bool rounds = false;
+                        if (any_hit) {
+                            uint32_t mine = 0;
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                                for (int gq = 0; gq < 4; ++gq) {
+                                    const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
+                                    if (!__any(ghit)) continue;
 #pragma unroll
                                     for (int g3 = 0; g3 < 4; ++g3)
 #pragma unroll
-                                        for (int rt = 0; rt < 4; ++rt) {
-                                            const int32_t hi = acc[rt][ct][4 * gq + g3];
-                                            const bool surv = ghit && hi >= Thi[ct];
-                                            const bool pick = surv && seen == taken;
-                                            sel_hi = pick ? hi : sel_hi;
-                                            sel_site = pick ? (4 * g3 + rt) : sel_site;
-                                            seen += surv ? 1 : 0;
-                                        }
-                                    const bool mine = sel_site >= 0;
-                                    const unsigned long long mm = __ballot(mine);
-                                    if (!mm) break;
-                                    taken += mine ? 1 : 0;
-                                    const uint32_t nm = (uint32_t)__popcll(mm);
-                                    pc_nsurv += probe ? nm : 0u;
-                                    if (ns + nm > (uint32_t)kI8hSurvCap) flush();
-                                    if (mine) {
-                                        const uint32_t slot = ns + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                                        const uint32_t site = (uint32_t)sel_site;
-                                        s.surv[wu][slot][0] = (uint32_t)sel_hi;
-                                        s.surv[wu][slot][1] = (uint32_t)tb + 4u * ((site >> 2) + 8u * (uint32_t)gq + 4u * (uint32_t)half) + (site & 3u);
-                                        s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
+                                        for (int rt = 0; rt < 4; ++rt) mine += (ghit && acc[rt][ct][4 * gq + g3] >= Thi[ct]) ? 1u : 0u;
+                                }
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+                            const uint32_t total_new = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+                            pc_nsurv += probe ? total_new : 0u;
+                            rounds = ns + total_new > (uint32_t)kI8hSurvCap;
+                            if (!rounds) {
+#pragma unroll
+                                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                                    for (int gq = 0; gq < 4; ++gq) {
+                                        const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
+                                        if (!__any(ghit)) continue;  // wave-uniform: most tiles touch one group of one query column
+#pragma unroll
+                                        for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                                            for (int rt = 0; rt < 4; ++rt) {
+                                                const int32_t hi = acc[rt][ct][4 * gq + g3];
+                                                const bool surv = ghit && hi >= Thi[ct];
+                                                const unsigned long long mm = __ballot(surv);
+                                                if (!mm) continue;
+                                                if (surv) {  // the lanes of a site write side by side: slot = length + rank among its survivors
+                                                    const uint32_t slot = ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                                                    s.surv[wu][slot][0] = (uint32_t)hi;
+                                                    s.surv[wu][slot][1] = (uint32_t)tb + 4u * ((uint32_t)g3 + 8u * (uint32_t)gq + 4u * (uint32_t)half) + (uint32_t)rt;
+                                                    s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
+                                                }
+                                                ns += (uint32_t)__popcll(mm);
+                                            }
                                     }
-                                    ns += nm;
+                            }
+                        }
+                        if (rounds || sync_flush || ns >= (uint32_t)kI8hFlushAt) {
+                            const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
+                            pc_nvis += probe ? 1u : 0u;
+                            ring_release();
+                            if (rounds) {
+#pragma unroll
+                                for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+                                    for (int gq = 0; gq < 4; ++gq) {
+                                        const bool ghit = hit[ct] && gbest[ct][gq] >= Thi[ct];
+                                        if (!__any(ghit)) continue;
+                                        int taken = 0;
+                                        while (true) {
+                                            int32_t sel_hi = 0;
+                                            int sel_site = -1, seen = 0;
+#pragma unroll
+                                            for (int g3 = 0; g3 < 4; ++g3)
+#pragma unroll
+                                                for (int rt = 0; rt < 4; ++rt) {
+                                                    const int32_t hi = acc[rt][ct][4 * gq + g3];
+                                                    const bool surv = ghit && hi >= Thi[ct];
+                                                    const bool pick = surv && seen == taken;
+                                                    sel_hi = pick ? hi : sel_hi;
+                                                    sel_site = pick ? (4 * g3 + rt) : sel_site;
+                                                    seen += surv ? 1 : 0;
+                                                }
+                                            const bool mine = sel_site >= 0;
+                                            const unsigned long long mm = __ballot(mine);
+                                            if (!mm) break;
+                                            taken += mine ? 1 : 0;
+                                            const uint32_t nm = (uint32_t)__popcll(mm);
+                                            if (ns + nm > (uint32_t)kI8hSurvCap) flush();
+                                            if (mine) {
+                                                const uint32_t slot = ns + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                                                const uint32_t site = (uint32_t)sel_site;
+                                                s.surv[wu][slot][0] = (uint32_t)sel_hi;
+                                                s.surv[wu][slot][1] = (uint32_t)tb + 4u * ((site >> 2) + 8u * (uint32_t)gq + 4u * (uint32_t)half) + (site & 3u);
+                                                s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
+                                            }
+                                            ns += nm;
+                                        }
+                                    }
                                 }
                             }
-                        }
-                        flush();
-                        unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
-                        pc_npub += probe ? (uint32_t)(__popcll(admitted_by[0]) + __popcll(admitted_by[1])) : 0u;
-                        const unsigned long long pt1 = probe ? __builtin_readcyclecounter() : 0ull;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            unsigned long long m = admitted_by[ct];
-                            m = (m | (m >> 32)) & 0xffffffffull;
-                            while (m) {
-                                const int L = __builtin_ctzll(m);
-                                m &= m - 1;
-                                const size_t qg = q0 + 64 * wu + 32 * ct + L;  // wave-uniform
-                                gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane, kk, kmargin[qg]);
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t c = __hip_atomic_load(&s.cnt[64 * w + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        unsigned long long need = __ballot(c > cap - kGemmBurst);
-                        while (need) {
-                            const int j = __builtin_ctzll(need);
-                            need &= need - 1;
-                            const int qj = 64 * w + j;
-                            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
-                            uint32_t t;
-                            const uint32_t keep = wave_compact<R>(my_lists + (size_t)qj * cap, cj, KP, &t);
-                            if (lane == 0) {
-                                s.cnt[qj] = keep;
-                                s.thr[qj] = t;
-                                if (t > __hip_atomic_load(&gthr[q0 + qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                    __hip_atomic_fetch_max(&gthr[q0 + qj], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        // give the ring back: the fragments of the next two K-steps again (ring slot r holds K-step b_ks - 2 + r),
-                        // and nothing may be in flight when the K-loop's counted waits resume
-                        asm volatile("; innr operand ring reclaimed" ::: "memory");
-#pragma unroll
-                        for (int r = 0; r < kI8Lead; ++r) {
-                            const uint32_t kidx = (b_ks + 2u * nk - (uint32_t)kI8Lead + (uint32_t)r) % nk;
-                            issue_b_at(breg[r][0], breg[r][1], 0, kidx);
-                            issue_b_at(breg[r][2], breg[r][3], 1, kidx);
-                        }
-                        wait_all();
-#pragma unroll
-                        for (int r = 0; r < kI8Lead; ++r) {
-                            use_after<0>(breg[r][0], breg[r][1]);
-                            use_after<0>(breg[r][2], breg[r][3]);
-                        }
-                        if (probe) {
-                            const unsigned long long pt2 = __builtin_readcyclecounter();
-                            pc_visit += pt2 - pt0;
-                            pc_tail += pt2 - pt1;
+                            finish();
+                            ring_reclaim();
+                            if (probe) pc_visit += __builtin_readcyclecounter() - pt0;
                         }
                     }
                 }
@@ -987,7 +1083,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     }
     wait_all();
     __syncthreads();
-    if (MODE == 0 && (kI8hProbe & 4) && lane == 0) {
+    if (MODE == 0 && (kI8hProbe & (4 | 1)) && lane == 0) {
         atomicAdd(errflag + 8, pc_nvis);
         atomicAdd(errflag + 9, pc_nsurv);
         atomicAdd(errflag + 10, pc_npub);

@@ -214,6 +214,12 @@ struct innr_batch {
     float max_norm = 0.0f;
     uint64_t index_base = 0;
     std::vector<float> dimvar;  // batch_dimension_variance, computed once (batch.rs:572)
+    // Row-major copy Vr[i*Dr + d] (Dr = D rounded up to 4), built on the first call that has MANY candidates per query to
+    // re-score exactly (the completion pass, k beyond the candidate lists): in the dimension-major store a candidate's D values
+    // lie in D different cache lines (64 B fetched per 4 B used); here they are contiguous. Always owned; + N*Dr*4 bytes.
+    float* Vr = nullptr;
+    size_t Dr = 0;
+    bool vr_refused = false;  // it did not fit: do not try again on every call
     // scalar-quantised corpus (scalar.rs): codes C8[d*ldN + i] instead of V, with the collection's params
     uint8_t* C8 = nullptr;
     float alpha = 1.0f, offset = 0.0f;
@@ -778,7 +784,100 @@ static innr_status redo_batch(innr_batch* b, int metric, const float* dQ, const 
 // the exact engine, 8 per corpus pass: 1024 queries = 128 passes = 0.84 s at C2; the completion pass is one GEMM pass (~0.11 s)
 // plus a few hundred exact dots per query. Queries whose list overflows kCollectCap (or whose x_k / E is not finite) stay
 // unresolved and take the exact engine as before.
-constexpr uint32_t kCollectCap = kSelSlots;  // 4096 candidates per query: one LDS sort window (kernels_topk.h)
+constexpr uint32_t kCollectCap = 65536;  // candidates per query the completion pass can hold (256 KiB of indices per query)
+
+// PDX -> row-major: Vr[i*Dr + d] = V[d*ldN + i], 32 x 32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void pdx_to_rows_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D, float* __restrict__ Vr,
+                                                           uint32_t Dr) {
+    __shared__ float t[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t i0 = (size_t)blockIdx.x * 32;
+    const uint32_t d0 = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t d = d0 + ty + 8 * r;
+        t[ty + 8 * r][tx] = (d < D && i0 + tx < N) ? V[(size_t)d * ldN + i0 + tx] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t i = i0 + ty + 8 * r;
+        const uint32_t d = d0 + tx;
+        if (i < N && d < Dr) Vr[i * Dr + d] = t[tx][ty + 8 * r];
+    }
+}
+
+// exact scores of collected candidates from the ROW-MAJOR copy. One lane per candidate (the reference's sum is a chain: d
+// ascending, fl(acc + fl(q_d * v_d))), but the rows are FETCHED by the whole wave: 64 dimensions of 64 candidate rows per step
+// as sixteen 16-byte loads per lane -- a quarter-wave covers one row's 256 contiguous bytes -- staged through LDS (row stride 65
+// words: the per-lane walk along a row is conflict-free), the query through wave-uniform (scalar) loads. A lane reading its own
+// row 16 bytes at a time touched 64 cache lines per load instruction: 65 ms for the 33 M candidates of the LCG bench row
+// (1.6 TB/s); staged: see DESIGN.md.
+template <int MET>
+__global__ __launch_bounds__(256) void collect_scores_rows_kernel(const float* __restrict__ Vr, uint32_t Dr, uint32_t D,
+                                                                   const float* __restrict__ Qm, const float* __restrict__ norms,
+                                                                   const float* __restrict__ qnorm, const uint32_t* __restrict__ clist,
+                                                                   const uint32_t* __restrict__ ccnt, uint32_t cap,
+                                                                   uint64_t* __restrict__ keys) {
+    constexpr bool COS = MET == 1, L2 = MET == 2;
+    __shared__ float stage[4][64][65];
+    const uint32_t q = blockIdx.y;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n = ccnt[q] < cap ? ccnt[q] : cap;
+    const uint32_t base = blockIdx.x * 256 + 64 * (uint32_t)w;
+    if (base >= n) return;  // (wave-uniform; no block-level synchronisation below)
+    const uint32_t slot = base + (uint32_t)lane;
+    const bool on = slot < n;
+    const uint32_t i = clist[(size_t)q * cap + (on ? slot : base)];  // idle lanes re-read the wave's first row
+    const float* qv = Qm + (size_t)q * D;
+    float (*st)[65] = stage[w];
+    const int sub = lane >> 4, l16 = lane & 15;
+    float acc = 0.0f;
+    for (uint32_t d0 = 0; d0 < D; d0 += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const uint32_t ir = (uint32_t)__shfl((int)i, 4 * rr + sub, 64);
+            const uint32_t d = d0 + 4 * (uint32_t)l16;
+            v[rr] = d < Dr ? *reinterpret_cast<const float4*>(Vr + (size_t)ir * Dr + d) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            float* p = &st[4 * rr + sub][4 * l16];
+            p[0] = v[rr].x; p[1] = v[rr].y; p[2] = v[rr].z; p[3] = v[rr].w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t lim = D - d0 < 64u ? D - d0 : 64u;
+        if (lim == 64u) {
+#pragma unroll 16
+            for (uint32_t j = 0; j < 64; ++j) {
+                const float x = st[lane][j], qd = qv[d0 + j];
+                if (L2) {
+                    const float df = ex::sub_keepnan(qd, x);
+                    acc = ex::mad2(acc, df, df);
+                } else {
+                    acc = ex::mad2(acc, qd, x);
+                }
+            }
+        } else {
+            for (uint32_t j = 0; j < lim; ++j) {
+                const float x = st[lane][j], qd = qv[d0 + j];
+                if (L2) {
+                    const float df = ex::sub_keepnan(qd, x);
+                    acc = ex::mad2(acc, df, df);
+                } else {
+                    acc = ex::mad2(acc, qd, x);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (COS) {
+        const float qn = qnorm[q], vn = norms[i];
+        acc = (qn < INNR_NORM_EPSILON) ? 0.0f : ((vn > INNR_NORM_EPSILON) ? ex::div(acc, ex::mul(qn, vn)) : 0.0f);
+    }
+    if (on) keys[(size_t)q * cap + slot] = cand_make(score_pref<L2>(acc), i);
+}
 
 __global__ void gather_kth_kernel(const float* __restrict__ scores, const uint32_t* __restrict__ map, uint32_t n, uint32_t k,
                                   float* __restrict__ out) {
@@ -818,26 +917,48 @@ __global__ __launch_bounds__(256) void collect_scores_kernel(const float* __rest
     keys[(size_t)q * cap + slot] = cand_make(score_pref<L2>(acc), i);
 }
 
-// best kout of a query's n <= kSelSlots exact composites: one workgroup per query, one LDS bitonic sort
+// best kout (<= kSelSlots) of a query's n exact composites: one workgroup per query (wg_segment_topk: LDS sort, or radix select + sort)
 __global__ __launch_bounds__(kSelThreads) void segment_topk_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ccnt,
                                                                     uint32_t cap, uint32_t kout, bool smaller_is_better,
                                                                     uint64_t index_base, uint64_t* __restrict__ out_idx,
                                                                     float* __restrict__ out_score, uint32_t* __restrict__ unresolved) {
     __shared__ uint64_t s[kSelSlots];
+    __shared__ uint32_t hist[258];
     const uint32_t q = blockIdx.x;
     const uint32_t n = ccnt[q];
     if (n > cap || n < kout) {  // overflow (or a threshold that was not a bound: non-finite scores): the exact engine decides
         if (threadIdx.x == 0) unresolved[q] = 1u;
         return;
     }
-    const int np = next_pow2_i((int)n > 1 ? (int)n : 1);
-    for (int e = threadIdx.x; e < np; e += kSelThreads) s[e] = (uint32_t)e < n ? keys[(size_t)q * cap + e] : 0ull;
-    __syncthreads();
-    wg_bitonic_desc(s, np);
+    wg_segment_topk(keys + (size_t)q * cap, n, kout, s, hist);
     for (uint32_t r = threadIdx.x; r < kout; r += kSelThreads) {
         out_idx[(size_t)q * kout + r] = index_base + cand_idx(s[r]);
         out_score[(size_t)q * kout + r] = pref_score(cand_pref(s[r]), smaller_is_better);
     }
+}
+
+// the row-major copy of an f32 batch (innr_batch::Vr), if it exists or fits with room to spare (twice its size + 8 GiB free)
+static innr_status ensure_rowmajor(innr_batch* b, bool* have) {
+    *have = b->Vr != nullptr;
+    if (b->Vr || b->vr_refused || !b->V || b->N == 0 || b->D == 0) return INNR_OK;
+    const size_t Dr = round_up(b->D, 4), bytes = b->N * Dr * sizeof(float);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + ((size_t)8 << 30)) {
+        b->vr_refused = true;
+        return INNR_OK;
+    }
+    if (hipMalloc((void**)&b->Vr, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        b->Vr = nullptr;
+        b->vr_refused = true;
+        return INNR_OK;
+    }
+    b->Dr = Dr;
+    dim3 grid((unsigned)((b->N + 31) / 32), (unsigned)((Dr + 31) / 32));
+    pdx_to_rows_kernel<<<grid, 256, 0, b->ctx->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, b->Vr, (uint32_t)Dr);
+    INNR_HIP_CHECK(hipGetLastError());
+    *have = true;
+    return INNR_OK;
 }
 
 // redo: the unproven queries (ascending), d_out_*: the first pass' output (its k-th score per query is read, the resolved
@@ -901,10 +1022,18 @@ static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, cons
     uint64_t* keys = c->sort_keys.as<uint64_t>();
     const uint32_t* clist = c->lists.as<uint32_t>();
     const uint32_t* ccnt = c->counts.as<uint32_t>();
-    const dim3 sg(kCollectCap / 256, (unsigned)nr);
-    if (cos) collect_scores_kernel<1><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-    else if (l2) collect_scores_kernel<2><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-    else collect_scores_kernel<0><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    const dim3 sg(kCollectCap / 256, (unsigned)nr);  // (blocks beyond a query's list length return at once)
+    bool rows = false;
+    INNR_TRY(ensure_rowmajor(b, &rows));  // contiguous candidate rows instead of D cache lines each, when the copy exists or fits
+    if (rows) {
+        if (cos) collect_scores_rows_kernel<1><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+        else if (l2) collect_scores_rows_kernel<2><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+        else collect_scores_rows_kernel<0><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    } else {
+        if (cos) collect_scores_kernel<1><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+        else if (l2) collect_scores_kernel<2><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+        else collect_scores_kernel<0><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
+    }
     INNR_HIP_CHECK(hipGetLastError());
     INNR_TRY(c->sel_cnt.ensure(nr * sizeof(uint32_t)));
     uint32_t* unres = c->sel_cnt.as<uint32_t>();
@@ -1425,6 +1554,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->invn) (void)hipFree(b->invn);
     if (b->sqn) (void)hipFree(b->sqn);
     if (b->max_norm_bits) (void)hipFree(b->max_norm_bits);
+    if (b->Vr) (void)hipFree(b->Vr);
     if (b->Ab) (void)hipFree(b->Ab);
     if (b->Abn) (void)hipFree(b->Abn);
     if (b->Abl) (void)hipFree(b->Abl);

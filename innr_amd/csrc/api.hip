@@ -88,6 +88,7 @@ struct innr_tuning {
     long fail_local_search = 0;  // TEST switch of the sharded calls: this rank's local search reports a failure
     long no_completion = 0;      // unproven queries of the f32 engine: straight to the KP retry / exact engine (no completion pass)
     long trace = 0;              // diagnostics of the redo paths on stderr (list lengths of the completion pass, ...)
+    long no_rows_copy = 0;       // never build the row-major copy: the completion pass re-scores by column gathers (what a full HBM does)
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -97,7 +98,7 @@ static const TuneName kTuneNames[] = {
     {"i8_two_limb", &innr_tuning::i8_two_limb}, {"no_auto_bf16", &innr_tuning::no_auto_bf16},
     {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
-    {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace},
+    {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -239,6 +240,7 @@ struct innr_batch {
     char* Ai8n = nullptr;
     float i8_alpha = 0.0f, i8_offset = 0.0f, i8n_alpha = 0.0f, i8n_offset = 0.0f;
     bool i8_weak = false, i8n_weak = false;  // most proofs failed on this corpus (a range blown up by outliers): AUTO stops picking the filter
+    uint32_t i8_weak_skips = 0;              // AUTO calls that skipped the int8 filter since (every 64th tries it again)
 };
 
 namespace innr {
@@ -724,6 +726,9 @@ __global__ void gather_f32_kernel(const float* __restrict__ src, const uint32_t*
 static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, const float* dQn,
                             uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept,
                             float* gemm_ms, bool bf16 = false, uint32_t kp_force = 0, int level = 0);
+static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
+                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served,
+                              const float* collect_kth = nullptr, uint32_t* d_unresolved = nullptr);
 
 // Queries whose margin proof failed (`redo`: their indices, ascending): gathered into ONE contiguous block and redone
 // together -- on the exact engine, 8 queries per corpus pass (via_gemm_kp == 0), or once more on the f32 GEMM engine
@@ -939,8 +944,8 @@ __global__ __launch_bounds__(kSelThreads) void segment_topk_kernel(const uint64_
 
 // the row-major copy of an f32 batch (innr_batch::Vr), if it exists or fits with room to spare (twice its size + 8 GiB free)
 static innr_status ensure_rowmajor(innr_batch* b, bool* have) {
-    *have = b->Vr != nullptr;
-    if (b->Vr || b->vr_refused || !b->V || b->N == 0 || b->D == 0) return INNR_OK;
+    *have = b->Vr != nullptr && !b->ctx->tune.no_rows_copy;
+    if (b->Vr || b->vr_refused || b->ctx->tune.no_rows_copy || !b->V || b->N == 0 || b->D == 0) return INNR_OK;
     const size_t Dr = round_up(b->D, 4), bytes = b->N * Dr * sizeof(float);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + ((size_t)8 << 30)) {
@@ -961,15 +966,50 @@ static innr_status ensure_rowmajor(innr_batch* b, bool* have) {
     return INNR_OK;
 }
 
-// redo: the unproven queries (ascending), d_out_*: the first pass' output (its k-th score per query is read, the resolved
-// queries' rows are overwritten). *unresolved: those that still need the exact engine.
-static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, const std::vector<uint32_t>& redo, size_t kout,
-                                uint64_t* d_out_idx, float* d_out_score, std::vector<uint32_t>* unresolved, float* gemm_ms) {
+// The second half of a completion pass, whatever filter collected: exact scores of every collected candidate (row-major copy when
+// it exists or fits, else column gathers), best kout per query -> d_out_* [Q][kout]; d_unresolved[q] = 1 for overflowed lists.
+// clist / ccnt: c->lists / c->counts as the collect-mode kernels left them; Qm: the queries the exact scores are taken with.
+static innr_status collect_finish(innr_batch* b, int metric, const float* Qm, const float* qnorm, size_t nq, size_t kout,
+                                  uint64_t* d_out_idx, float* d_out_score, uint32_t* d_unresolved) {
+    innr_ctx* c = b->ctx;
+    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
+    const size_t D = b->D;
+    INNR_TRY(c->sort_keys.ensure(nq * (size_t)kCollectCap * sizeof(uint64_t)));
+    uint64_t* keys = c->sort_keys.as<uint64_t>();
+    const uint32_t* clist = c->lists.as<uint32_t>();
+    const uint32_t* ccnt = c->counts.as<uint32_t>();
+    const dim3 sg(kCollectCap / 256, (unsigned)nq);  // (blocks beyond a query's list length return at once)
+    bool rows = false;
+    INNR_TRY(ensure_rowmajor(b, &rows));  // contiguous candidate rows instead of D cache lines each, when the copy exists or fits
+    if (rows) {
+        if (cos) collect_scores_rows_kernel<1><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+        else if (l2) collect_scores_rows_kernel<2><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+        else collect_scores_rows_kernel<0><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+    } else {
+        if (cos) collect_scores_kernel<1><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+        else if (l2) collect_scores_kernel<2><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+        else collect_scores_kernel<0><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qm, b->norms, qnorm, clist, ccnt, kCollectCap, keys);
+    }
+    INNR_HIP_CHECK(hipGetLastError());
+    INNR_HIP_CHECK(hipMemsetAsync(d_unresolved, 0, nq * sizeof(uint32_t), c->stream));
+    segment_topk_kernel<<<(unsigned)nq, kSelThreads, 0, c->stream>>>(keys, ccnt, kCollectCap, (uint32_t)kout, l2, b->index_base, d_out_idx,
+                                                                    d_out_score, d_unresolved);
+    INNR_HIP_CHECK(hipGetLastError());
+    if (c->tune.trace) {
+        std::vector<uint32_t> cnt(nq);
+        INNR_HIP_CHECK(hipMemcpyAsync(cnt.data(), ccnt, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        std::sort(cnt.begin(), cnt.end());
+        fprintf(stderr, "completion pass: %zu queries, collected per query min %u / median %u / max %u (capacity %u), rows copy %d\n", nq,
+                cnt.front(), cnt[nq / 2], cnt.back(), kCollectCap, (int)rows);
+    }
+    return INNR_OK;
+}
+
+// gather the unproven queries and their k-th exact scores into c->cmpl (map, q, qn = x_k)
+static innr_status collect_gather(innr_batch* b, const float* dQ, const std::vector<uint32_t>& redo, size_t kout, const float* d_out_score) {
     innr_ctx* c = b->ctx;
     const size_t nr = redo.size(), D = b->D;
-    unresolved->clear();
-    if (nr == 0) return INNR_OK;
-    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     innr_ctx::RedoBufs& rb = c->cmpl;  // its own set: a nested pass (redo_batch -> knn_mfma) runs while redo[level] is live
     INNR_TRY(rb.map.ensure(nr * sizeof(uint32_t)));
     INNR_TRY(rb.q.ensure(std::max<size_t>(nr * D, 1) * sizeof(float)));
@@ -983,10 +1023,64 @@ static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, cons
     INNR_HIP_CHECK(hipGetLastError());
     gather_kth_kernel<<<(unsigned)((nr + 255) / 256), 256, 0, c->stream>>>(d_out_score, map, (uint32_t)nr, (uint32_t)kout, rb.qn.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
+    return INNR_OK;
+}
+// resolved rows back to their places; the unresolved ones (rewritten by the next engine afterwards) are listed
+static innr_status collect_scatter(innr_batch* b, const std::vector<uint32_t>& redo, size_t kout, uint64_t* d_out_idx, float* d_out_score,
+                                   const uint32_t* d_unres, std::vector<uint32_t>* unresolved) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size();
+    innr_ctx::RedoBufs& rb = c->cmpl;
+    std::vector<uint32_t> un(nr);
+    INNR_HIP_CHECK(copy_out(c, un.data(), d_unres, nr * sizeof(uint32_t)));
+    INNR_HIP_CHECK(ctx_sync(c));
+    scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(rb.idx.as<uint64_t>(), rb.sc.as<float>(), rb.map.as<uint32_t>(),
+                                                                                   (uint32_t)nr, (uint32_t)kout, d_out_idx, d_out_score);
+    INNR_HIP_CHECK(hipGetLastError());
+    unresolved->clear();
+    for (size_t r = 0; r < nr; ++r)
+        if (un[r]) unresolved->push_back(redo[r]);
+    return INNR_OK;
+}
+
+// the int8 filter's completion pass (f32 corpus, dot / cosine)
+static innr_status knn_complete_i8(innr_batch* b, int metric, const float* dQ, const std::vector<uint32_t>& redo, size_t kout,
+                                   uint64_t* d_out_idx, float* d_out_score, std::vector<uint32_t>* unresolved, float* gemm_ms) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size();
+    unresolved->clear();
+    if (nr == 0) return INNR_OK;
+    INNR_TRY(collect_gather(b, dQ, redo, kout, d_out_score));
+    innr_ctx::RedoBufs& rb = c->cmpl;
+    INNR_TRY(c->sel_cnt.ensure(nr * sizeof(uint32_t)));
+    uint32_t nf = 0, kept = 0;
+    bool served = false;
+    INNR_TRY(knn_f32_i8(b, metric, rb.q.as<float>(), nr, kout, rb.idx.as<uint64_t>(), rb.sc.as<float>(), &nf, &kept, gemm_ms, &served,
+                        rb.qn.as<float>(), c->sel_cnt.as<uint32_t>()));
+    if (!served) {  // (cannot happen after a first pass of the same filter) nothing was resolved
+        *unresolved = redo;
+        return INNR_OK;
+    }
+    INNR_TRY(collect_scatter(b, redo, kout, d_out_idx, d_out_score, c->sel_cnt.as<uint32_t>(), unresolved));  // (synchronises)
+    float ms = 0.0f;
+    if (gemm_ms && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms += ms;
+    return INNR_OK;
+}
+
+// redo: the unproven queries (ascending), d_out_*: the first pass' output (its k-th score per query is read, the resolved
+// queries' rows are overwritten). *unresolved: those that still need the exact engine.
+static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, const std::vector<uint32_t>& redo, size_t kout,
+                                uint64_t* d_out_idx, float* d_out_score, std::vector<uint32_t>* unresolved, float* gemm_ms) {
+    innr_ctx* c = b->ctx;
+    const size_t nr = redo.size();
+    unresolved->clear();
+    if (nr == 0) return INNR_OK;
+    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
+    INNR_TRY(collect_gather(b, dQ, redo, kout, d_out_score));
+    innr_ctx::RedoBufs& rb = c->cmpl;
     const float* kth = rb.qn.as<float>();  // x_k per unproven query
     const float* Qr = rb.q.as<float>();
     GemmPlan p = plan_gemm(b, nr, kout, (!cos && !l2 && nr > 256) ? 8u : 4u, !cos && !l2);
-    p.KP = 32;  // (the slots of prep_gthr are not used in collect mode)
     if (cos) INNR_TRY(ensure_invnorms(b));
     if (l2) INNR_TRY(ensure_sqnorms(b));
     INNR_TRY(prep_queries(b, p, Qr, nr, cos));  // K-major queries, exact norms (c->q_norm), cosine: 1/|q| at c->misc
@@ -1017,49 +1111,11 @@ static innr_status knn_complete(innr_batch* b, int metric, const float* dQ, cons
     else if (l2) INNR_TRY((launch_gemm<kGemmL2, 2>(b, pl, nr, c->q_kmajor.as<float>(), b->sqn, invq, nullptr, 0, thr)));
     else INNR_TRY((launch_gemm<kGemmDot, 2>(b, pl, nr, c->q_kmajor.as<float>(), nullptr, nullptr, nullptr, 0, thr)));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    // exact scores of everything collected, best k per query
-    INNR_TRY(c->sort_keys.ensure(nr * (size_t)kCollectCap * sizeof(uint64_t)));
-    uint64_t* keys = c->sort_keys.as<uint64_t>();
-    const uint32_t* clist = c->lists.as<uint32_t>();
-    const uint32_t* ccnt = c->counts.as<uint32_t>();
-    const dim3 sg(kCollectCap / 256, (unsigned)nr);  // (blocks beyond a query's list length return at once)
-    bool rows = false;
-    INNR_TRY(ensure_rowmajor(b, &rows));  // contiguous candidate rows instead of D cache lines each, when the copy exists or fits
-    if (rows) {
-        if (cos) collect_scores_rows_kernel<1><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-        else if (l2) collect_scores_rows_kernel<2><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-        else collect_scores_rows_kernel<0><<<sg, 256, 0, c->stream>>>(b->Vr, (uint32_t)b->Dr, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-    } else {
-        if (cos) collect_scores_kernel<1><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-        else if (l2) collect_scores_kernel<2><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-        else collect_scores_kernel<0><<<sg, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)D, Qr, b->norms, c->q_norm.as<float>(), clist, ccnt, kCollectCap, keys);
-    }
-    INNR_HIP_CHECK(hipGetLastError());
     INNR_TRY(c->sel_cnt.ensure(nr * sizeof(uint32_t)));
-    uint32_t* unres = c->sel_cnt.as<uint32_t>();
-    INNR_HIP_CHECK(hipMemsetAsync(unres, 0, nr * sizeof(uint32_t), c->stream));
-    segment_topk_kernel<<<(unsigned)nr, kSelThreads, 0, c->stream>>>(keys, ccnt, kCollectCap, (uint32_t)kout, l2, b->index_base,
-                                                                    rb.idx.as<uint64_t>(), rb.sc.as<float>(), unres);
-    INNR_HIP_CHECK(hipGetLastError());
-    std::vector<uint32_t> un(nr);
-    INNR_HIP_CHECK(copy_out(c, un.data(), unres, nr * sizeof(uint32_t)));
-    INNR_HIP_CHECK(ctx_sync(c));
+    INNR_TRY(collect_finish(b, metric, Qr, c->q_norm.as<float>(), nr, kout, rb.idx.as<uint64_t>(), rb.sc.as<float>(), c->sel_cnt.as<uint32_t>()));
+    INNR_TRY(collect_scatter(b, redo, kout, d_out_idx, d_out_score, c->sel_cnt.as<uint32_t>(), unresolved));  // (synchronises)
     float ms = 0.0f;
     if (gemm_ms && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) *gemm_ms += ms;
-    // resolved rows back to their places (the unresolved ones are rewritten by the exact engine afterwards)
-    scatter_results_kernel<<<(unsigned)((nr * kout + 255) / 256), 256, 0, c->stream>>>(rb.idx.as<uint64_t>(), rb.sc.as<float>(), map, (uint32_t)nr,
-                                                                                   (uint32_t)kout, d_out_idx, d_out_score);
-    INNR_HIP_CHECK(hipGetLastError());
-    for (size_t r = 0; r < nr; ++r)
-        if (un[r]) unresolved->push_back(redo[r]);
-    if (c->tune.trace) {
-        std::vector<uint32_t> cnt(nr);
-        INNR_HIP_CHECK(hipMemcpyAsync(cnt.data(), ccnt, nr * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
-        std::sort(cnt.begin(), cnt.end());
-        fprintf(stderr, "knn_complete: %zu queries, collected per query min %u / median %u / max %u (capacity %u), %zu unresolved\n", nr,
-                cnt.front(), cnt[nr / 2], cnt.back(), kCollectCap, unresolved->size());
-    }
     return INNR_OK;
 }
 
@@ -1924,8 +1980,7 @@ static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, siz
 // the int8 filter in front of an f32 corpus (defined with the int8 engine further down)
 static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout);
 static size_t f32_i8_copy_bytes(const innr_batch* b);
-static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
-                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served);
+
 
 extern "C" {
 
@@ -1960,13 +2015,15 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
         // a batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
         // everything else with room to spare (copies are kept for the batch's lifetime): the int8 one first (N*D bytes, the
         // faster kernel), else the bf16 one (N*D*2 bytes).
-        if (engine == INNR_KNN_MFMA && Q >= 128 && pick_kp(4 * kout + 64, 0) <= 256 && !b->ctx->tune.no_auto_bf16) {
+        if (engine == INNR_KNN_MFMA && Q >= 128 && kout <= INNR_MAX_K && !b->ctx->tune.no_auto_bf16) {
             const bool cosm = metric == INNR_METRIC_COSINE;
             const int bfv = cosm ? kBfCos : (metric == INNR_METRIC_L2SQ ? kBfL2 : kBfDot);
             size_t free_b = 0, total_b = 0;
             const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
             const size_t slack = (size_t)8 << 30;
-            if (f32_i8_eligible(b, metric, Q, kout) && !b->ctx->tune.no_auto_i8 && !(cosm ? b->i8n_weak : b->i8_weak) &&
+            // (a corpus marked weak -- its proofs failed on the int8 filter -- is looked at again every 64th call: data change)
+            const bool weak = (cosm ? b->i8n_weak : b->i8_weak) && (++b->i8_weak_skips % 64u) != 0;
+            if (f32_i8_eligible(b, metric, Q, kout) && !b->ctx->tune.no_auto_i8 && !weak &&
                 ((cosm ? b->Ai8n : b->Ai8) != nullptr || (have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
                 engine = INNR_KNN_MFMA_I8;
             else if ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
@@ -2553,9 +2610,9 @@ struct I8Plan {
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
     bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
 };
-static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0) {
+static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0, bool one_limb = false) {
     I8Plan p;
-    p.two = i8_two_limb(b->ctx, kout) || kp_override > 128;
+    p.two = !one_limb && (i8_two_limb(b->ctx, kout) || kp_override > 128);  // (collect mode: always the one-limb kernel)
     const size_t bq = p.two ? (size_t)kI8BQ : (size_t)kI8hBQ;  // queries per block tile
     p.Qpad = round_up(Q, bq);
     p.nqt = (uint32_t)(p.Qpad / bq);
@@ -2586,7 +2643,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     uint32_t* gslots = nullptr;
     size_t nslot = 0;
     if (!kmargin) kk = 0;
-    INNR_TRY(prep_gthr(c, p.Qpad, p.KP, seed, nreal_q, kmargin, &gslots, &nslot));
+    INNR_TRY(prep_gthr(c, p.Qpad, MODE == 2 ? 32u : p.KP, seed, nreal_q, kmargin, &gslots, &nslot));  // (MODE 2: only the bounds are used)
     const bool two = p.two;
 #define INNR_I8_ARGS                                                                                                      \
     corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
@@ -2598,6 +2655,8 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     } while (0)
     if constexpr (MODE == 1) {
         INNR_I8_LAUNCH(6);
+    } else if constexpr (MODE == 2) {  // collect (the completion pass): one-limb kernel, the list geometry plays no part
+        gemm_i8h_filter_kernel<6, 2><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);
     } else {
         switch (p.cap) {
             case 384: INNR_I8_LAUNCH(6); break;
@@ -2691,6 +2750,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
 }
 
 #ifdef INNR_TEST_HOOKS
+// (MODE 1 of the int8 kernels exists in this build only)
 // Test hook (not part of the ABI): dense approximate score matrix of the int8 engine, out[q*N + i] = A_q V(q, i) + B_q, and
 // the per-query constants qc[4][Qpad] -- to check the int8 MFMA operand layout and the limb arithmetic exactly.
 extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, size_t Q, size_t D, float* out, float* qc_out,
@@ -2726,7 +2786,7 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
 // is PROVEN against bound = query quantisation + (alpha / 510) |q|_1 + the reference's own accumulation error; unproven queries
 // go through the f32 GEMM engine as one batch, like the bf16 filter's.
 static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout) {
-    return b->V && metric != INNR_METRIC_L2SQ && pick_kp(4 * kout + 64, 0) <= 256 && b->D >= 1 && b->D <= 65535 &&
+    return b->V && metric != INNR_METRIC_L2SQ && kout <= INNR_MAX_K && b->D >= 1 && b->D <= 65535 &&
            i8_limb_r1((uint32_t)b->D, 8) >= 1 && i8_limb_r1((uint32_t)b->D, (uint32_t)kI8hS) >= 1 && b->ldN < ((size_t)1 << 31) &&
            Q < ((size_t)1 << 24) && b->gemm_ok;
 }
@@ -2778,8 +2838,13 @@ static innr_status ensure_f32_i8_corpus(innr_batch* b, bool normalised, bool* us
 }
 
 // *served = false: the engine does not apply to this corpus (constant values): the caller takes the f32 engine
-static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
-                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served) {
+// collect_kth != null: the COMPLETION pass of this filter (cf. knn_complete): dQ are the unproven queries (gathered), collect_kth[j]
+// = the k-th best EXACT score query j has so far (a lower bound of the true one); the kernel runs in collect mode with the fixed
+// thresholds x_k - E_j, everything collected is re-scored from the row-major copy and the best k written to d_out_* [Q][kout];
+// d_unresolved[j] = 1 where the list overflowed (those queries go on to the f32 engine).
+innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t Q, size_t kout, uint64_t* d_out_idx,
+                             float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served,
+                             const float* collect_kth, uint32_t* d_unresolved) {
     innr_ctx* c = b->ctx;
     const bool cos = metric == INNR_METRIC_COSINE;
     *served = false;
@@ -2791,7 +2856,11 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     if (!usable) return INNR_OK;
     *served = true;
     const float alpha = cos ? b->i8n_alpha : b->i8_alpha, offset = cos ? b->i8n_offset : b->i8_offset;
-    const I8Plan p = plan_i8(b, Q, kout, pick_kp(4 * kout + 64, 0));
+    // Lists of 4k + 64 let the k-th exact score clear the KP-th approximate one by a visible margin (k <= 48); beyond that the
+    // lists hold k + 16 (one-limb kernel up to 128, two-limb kernel to 256), most proofs fail BY DESIGN and the completion pass
+    // (one more pass of this filter in collect mode) settles them: k = 100 at C2 needs ~450 candidates per query.
+    const bool direct = pick_kp(4 * kout + 64, 0) <= 256;
+    const I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? pick_kp(4 * kout + 64, 0) : pick_kp(kout, 16)), collect_kth != nullptr);
     // exact query norms; cosine: 1/||q|| and the normalised copy the filter multiplies; sum and L1 norm of what it multiplies
     INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
     INNR_TRY(c->tmp_norms.ensure(3 * p.Qpad * sizeof(float)));
@@ -2820,6 +2889,23 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
     const float* eq = qc + 3 * p.Qpad;
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
+    if (collect_kth) {
+        // ---- completion pass: fixed thresholds x_k - E_j, global lists, exact re-score of everything collected ----
+        INNR_TRY(c->seed_score.ensure(p.Qpad * sizeof(uint32_t)));
+        uint32_t* thr = c->seed_score.as<uint32_t>();
+        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(collect_kth, (uint32_t)Q, 1u, eq, thr, (uint32_t)p.Qpad, 0u);
+        INNR_HIP_CHECK(hipGetLastError());
+        INNR_TRY(c->lists.ensure(p.Qpad * (size_t)kCollectCap * sizeof(uint32_t)));
+        INNR_TRY(c->counts.ensure(p.Qpad * sizeof(uint32_t)));
+        INNR_HIP_CHECK(hipMemsetAsync(c->counts.p, 0, p.Qpad * sizeof(uint32_t), c->stream));
+        I8Plan pl = p;
+        pl.KP = kCollectCap;
+        INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+        INNR_TRY(launch_gemm_i8<2>(b, pl, Q, qc, nullptr, 0, thr, cos ? b->Ai8n : b->Ai8));
+        INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+        INNR_TRY(collect_finish(b, metric, dQ, c->q_norm.as<float>(), Q, kout, d_out_idx, d_out_score, d_unresolved));
+        return INNR_OK;  // (the caller reads ev[2..3] once it has synchronised)
+    }
     const uint32_t* seed = nullptr;
     const size_t kSeedN = seed_prefix_rows(c, true, Q);
     if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
@@ -2868,10 +2954,23 @@ static innr_status knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t
         if (fb[q]) redo.push_back((uint32_t)q);
     *nfallback = (uint32_t)redo.size();
     *kept = p.KP;
-    if (Q >= 16 && redo.size() * 2 > Q) (cos ? b->i8n_weak : b->i8_weak) = true;  // AUTO takes the bf16 filter on this corpus from now on
-    if (!redo.empty())  // one batch on the f32 GEMM engine (its own proof, the exact engine behind it)
+    // (lists sized for a direct proof that mostly fail: the corpus' range is blown up by outliers; AUTO takes the bf16 filter,
+    //  whose error is relative, on this corpus from now on -- and looks at the int8 one again every 64th call, innr_batch_knn_dev)
+    if (direct && Q >= 16) (cos ? b->i8n_weak : b->i8_weak) = redo.size() * 2 > Q;
+    // ONE more pass of this filter in collect mode settles the unproven queries (k beyond the direct lists: nearly all of them)
+    if (redo.size() > 8 && !c->tune.no_completion) {
+        std::vector<uint32_t> still;
+        INNR_TRY(knn_complete_i8(b, metric, dQ, redo, kout, d_out_idx, d_out_score, &still, gemm_ms));
+        redo.swap(still);
+    }
+    if (!redo.empty()) {  // one batch on the f32 GEMM engine (its own proof, completion pass and the exact engine behind it)
+        if (cos) {  // (the completion pass used the query workspace: the exact norms of the whole batch again)
+            query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+            INNR_HIP_CHECK(hipGetLastError());
+        }
         INNR_TRY(redo_batch(b, metric, dQ, cos ? c->q_norm.as<float>() : nullptr, redo, kout, d_out_idx, d_out_score,
                             redo.size() >= 4 ? pick_kp(kout, 16) : 0u, 0));
+    }
     return INNR_OK;
 }
 

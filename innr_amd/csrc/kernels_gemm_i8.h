@@ -606,6 +606,9 @@ __device__ __forceinline__ int32_t i8_lo_dot(const char* __restrict__ Ai8, const
 }
 
 // MODE 0: fused top-k filter. MODE 1: dump the dense approximate score matrix (layout test; computes every low limb).
+// MODE 2: COLLECT (the completion pass, knn_f32_i8 in api.hip): every query has a FIXED threshold (gthr[q], set by the host: its
+//   k-th exact score so far, less its bound E) and every site whose exact V clears it is appended to the query's GLOBAL list
+//   (`lists` = uint32 indices [Qpad][KP], `counts` = uint32 [Qpad] lengths, KP = the capacity; an overfull list keeps counting).
 template <int R, int MODE>
 __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t ntiles, uint32_t N, uint32_t nk, size_t Qpad, uint32_t nqt,
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     __syncthreads();
 
     uint32_t tg_next[2] = {0u, 0u};
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
     }
@@ -886,11 +889,16 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                         const uint32_t o = f32_ord(__builtin_fmaf(c1 ? Aj[1] : Aj[0], (float)V, c1 ? Bj[1] : Bj[0]));
                                         if (o >= (c1 ? thr[1] : thr[0]) && i < N) {
                                             const int ql = 64 * w + 32 * (c1 ? 1 : 0) + C;
-                                            const bool pub = (i & (kI8hPubEvery - 1)) == 0;
-                                            admitted[0] = admitted[0] || (pub && !c1);
-                                            admitted[1] = admitted[1] || (pub && c1);
-                                            cand_append(my_lists + (size_t)ql * cap, &s.cnt[ql], cap, cand_make(o, i), errflag);
-                                            gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, i);
+                                            if (MODE == 2) {  // collect: the query's global list
+                                                const uint32_t pos = atomicAdd(counts + q0 + ql, 1u);
+                                                if (pos < KP) reinterpret_cast<uint32_t*>(lists)[(q0 + ql) * (size_t)KP + pos] = i;
+                                            } else {
+                                                const bool pub = (i & (kI8hPubEvery - 1)) == 0;
+                                                admitted[0] = admitted[0] || (pub && !c1);
+                                                admitted[1] = admitted[1] || (pub && c1);
+                                                cand_append(my_lists + (size_t)ql * cap, &s.cnt[ql], cap, cand_make(o, i), errflag);
+                                                gthr_raise(gslots + (q0 + ql) * (size_t)(kSlotMul * KP), kSlotMul * KP, o, i);
+                                            }
                                         }
                                     }
                                 }
@@ -915,6 +923,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         // finish what is queued, re-derive the chip-wide bounds that asked for it, compact lists that run short of room
                         auto finish = [&]() {
                             flush();
+                            if (MODE == 2) return;  // collect: no bound moves, no list to compact
                             unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
                             pc_npub += probe ? (uint32_t)(__popcll(admitted_by[0]) + __popcll(admitted_by[1])) : 0u;
                             const unsigned long long pt1 = probe ? __builtin_readcyclecounter() : 0ull;
@@ -1066,7 +1075,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         }
                     }
                 }
-                if (MODE == 0) {
+                if (MODE != 1) {
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) gload1_agent(tg_next[ct], gthr + q0 + 64 * wu + 32 * ct, 4u * (uint32_t)C);
                 }

@@ -58,7 +58,10 @@ def test_bf16_cosine_zero_norms_and_auto(B, innr):
     assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter (there is no int8 one for it)
     _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_AUTO, stats=st)
-    assert st.engine == innr.KNN_MFMA  # k > 48: the candidate lists of the bf16 filter would not fit
+    # k > 48: the int8 filter with lists of k + 16 and its completion pass (collect mode) behind them; same answers
+    assert st.engine == innr.KNN_MFMA_I8
+    _check_knn(B, innr, "dot", vb, data, qs, 100, innr.KNN_AUTO)
+    _check_knn(B, innr, "cos", vb, data, qs, 200, innr.KNN_MFMA_I8)  # lists of 256: the two-limb kernel, then the one-limb collect pass
 
 
 def test_bf16_filter_near_ties_are_redone_exactly(B, innr):
@@ -119,7 +122,7 @@ def test_bf16_filter_on_a_prefix_view(B, innr):
 def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     """INNR_KNN_MFMA_I8 on an f32 batch: a corpus with outliers (the global range is wide, the bound large: proofs fail,
     answers must not), a constant corpus (nothing to quantise against: the f32 engine serves it), non-finite values, squared L2
-    and k > 48 (served by the bf16 filter resp. the f32 engine), near-tie data, zero-norm rows / queries under cosine."""
+    (served by the bf16 filter), k > 48 (lists of k + 16 + the completion pass), near-tie data, zero-norm rows / queries under cosine."""
     rows, data = _corpus(70_000, 64, 13, uniform=True)
     qs = _queries(40, 64, 3, uniform=True)
     out = rows.copy()
@@ -140,7 +143,10 @@ def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_MFMA_I8, stats=st)
     assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_I8, stats=st)
-    assert st.engine == innr.KNN_MFMA
+    assert st.engine == innr.KNN_MFMA_I8  # k > 48: lists of k + 16 and the filter's completion pass
+    _check_knn(B, innr, "dot", vb, data, qs, 100, innr.KNN_MFMA_I8)
+    B.batch_knn_dot_multi(qs, vb, 241, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_EXACT  # beyond INNR_MAX_K: all scores + a sort
     _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_MFMA_I8)
     z = rows.copy()
     z[5] = 0.0

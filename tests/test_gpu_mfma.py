@@ -375,3 +375,41 @@ def test_knn_mfma_both_block_shapes_every_metric(B, innr, waves):
         for metric in ("dot", "cos", "l2"):
             vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, _queries(600, 64, 777, uniform=True), 10,
                             innr.KNN_MFMA)
+
+
+@pytest.mark.parametrize("metric", ["dot", "cos", "l2"])
+def test_completion_pass_every_path(B, innr, metric, ctx_option):
+    """Queries whose margin proof fails (here: every query -- the corpus holds each vector 40 times) are settled by ONE completion pass --
+    the GEMM kernel in collect mode with fixed thresholds, exact re-score of everything collected, radix select -- with the
+    answer the oracle gives; from the row-major copy, by column gathers (what a full HBM falls back to), and with the
+    completion pass switched off (exact engine, 8 queries per corpus pass)."""
+    base, _ = _corpus(1500, 96, 5, uniform=True)
+    rows = np.repeat(base, 40, axis=0)  # every vector 40 times: the cut at k = 10 lies inside a group of exactly equal scores
+    rows[::7] *= np.float32(1.0 + 2.0 ** -20)  # ... and near-equal ones around it
+    data = oracle.from_rows(rows)
+    qs = _queries(40, 96, 9, uniform=True)
+    st = innr.KnnStats()
+    fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
+    vb = _check_knn(B, innr, metric, rows, data, qs, 10, innr.KNN_MFMA)
+    fn(qs, vb, 10, engine=innr.KNN_MFMA, stats=st)
+    assert st.queries_fallback > 8  # the completion pass ran (up to 8 unproven queries take the exact engine directly)
+    ctx_option("no_rows_copy", 1)
+    _check_knn(B, innr, metric, vb, data, qs, 10, innr.KNN_MFMA)
+    ctx_option("no_completion", 1)
+    _check_knn(B, innr, metric, vb, data, qs, 10, innr.KNN_MFMA)
+    if metric != "l2":  # (which members of a tie group that straddles the cut survive is core::slice::binary_search's choice
+        _check_knn(B, innr, metric, vb, data, qs, 100, innr.KNN_MFMA)  # in TopK: DESIGN.md 2(a); k = 10 keeps the first ten either way)
+
+
+def test_k100_on_the_int8_filter_and_its_completion_pass(B, innr):
+    """k beyond the direct lists (4k + 64 > 256): lists of k + 16, most proofs fail by design, the int8 filter's own completion
+    pass (collect mode) settles them -- the reference benches k = 100 (benches/batch.rs:127,146)."""
+    rows, data = _corpus(150_000, 64, 3, uniform=True)
+    qs = _queries(200, 64, 11, uniform=True)
+    vb = None
+    for metric in ("dot", "cos"):
+        for k in (49, 100, 240):
+            vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, qs, k, innr.KNN_MFMA_I8)
+    st = innr.KnnStats()
+    B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_AUTO, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8

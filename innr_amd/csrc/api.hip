@@ -25,11 +25,12 @@
 
 namespace innr {  // sort_full.hip
 hipError_t full_sort_scratch_bytes(size_t n, size_t* bytes);
+size_t full_topk_out_capacity(size_t k);  // keys the `sorted` buffer must hold for the best k (the next power of two)
 hipError_t full_sort_scores(const float* scores, size_t n, bool smaller_is_better, uint64_t* keys, uint64_t* sorted,
-                            void* scratch, size_t scratch_bytes, hipStream_t stream, const uint8_t* mask = nullptr);
+                            void* scratch, size_t scratch_bytes, hipStream_t stream, const uint8_t* mask, size_t k);
 hipError_t segmented_sort_scratch_bytes(size_t nseg, size_t len, size_t* bytes);
-hipError_t segmented_sort_keys(const uint64_t* keys, uint64_t* sorted, size_t nseg, size_t len, uint32_t* off, void* scratch,
-                               size_t scratch_bytes, hipStream_t stream);
+hipError_t segmented_topk_keys(const uint64_t* keys, uint64_t* sorted, size_t nseg, size_t len, size_t k, uint64_t* tmp, void* scratch,
+                               hipStream_t stream);
 }  // namespace innr
 
 namespace innr {
@@ -1687,15 +1688,15 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
     INNR_ENTER(c);
     if (kc > 256) {
         // More candidates per query than a candidate list holds: exact scores of all of them (one thread per candidate,
-        // the reference's arithmetic order), then every query's kc composites sorted best-first in one segmented radix
-        // sort -- the reference's "score, stable sort, truncate" (scalar.rs:366-368 on top of batch.rs:754-763).
-        if (Q * kc > 0x7fffffffull) {
-            set_error("rerank: Q * candidates = %zu exceeds 2^31 - 1", Q * kc);
+        // the reference's arithmetic order), then the best k of every query's kc composites, best first (radix select + sort per
+        // query, sort_full.hip) -- the reference's "score, stable sort, truncate" (scalar.rs:366-368 on top of batch.rs:754-763).
+        if ((Q * kc + 255) / 256 > 0x7fffffffull) {
+            set_error("rerank: Q * candidates = %zu is beyond one launch", Q * kc);
             return INNR_E_UNSUPPORTED;
         }
         size_t tmp_bytes = 0;
         INNR_HIP_CHECK(segmented_sort_scratch_bytes(Q, kc, &tmp_bytes));
-        INNR_TRY(c->sort_keys.ensure(2 * Q * kc * sizeof(uint64_t)));
+        INNR_TRY(c->sort_keys.ensure((2 * Q * kc + full_topk_out_capacity(kout)) * sizeof(uint64_t)));
         INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
         INNR_TRY(c->q_norm.ensure(Q * sizeof(float)));
         INNR_TRY(c->misc.ensure((Q + 1) * sizeof(uint32_t) + 64));
@@ -1721,7 +1722,7 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
                                                               c->q_norm.as<float>(), d_cand, (uint32_t)Q, (uint32_t)kc,
                                                               b->index_base, keys, bad);
         INNR_HIP_CHECK(hipGetLastError());
-        INNR_HIP_CHECK(segmented_sort_keys(keys, keys + Q * kc, Q, kc, c->misc.as<uint32_t>(), c->sort_tmp.p, tmp_bytes, c->stream));
+        INNR_HIP_CHECK(segmented_topk_keys(keys, keys + Q * kc, Q, kc, kout, keys + 2 * Q * kc, c->sort_tmp.p, c->stream));
         const uint32_t total = (uint32_t)(Q * kout);
         emit_results_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(keys + Q * kc, (uint32_t)kc, (uint32_t)Q, (uint32_t)kout,
                                                                         met == 2, b->index_base, d_out_idx, d_out_score);
@@ -1922,24 +1923,20 @@ innr_status innr_batch_scores(innr_batch* b, int metric, const float* q, size_t 
 
 
 // k > INNR_MAX_K: more results than a candidate list holds. The reference's own algorithm, on the device: all N
-// scores of one query (scan_scores_kernel: the reference-order arithmetic the exact engine uses), a full sort of
-// (score, index) composites, truncate (batch.rs:754-763, 790-799, scalar.rs:383-392; for batch_knn's TopK,
-// batch.rs:398-409, the same k smallest in the same order up to ties at equal distances). One query at a time: the
-// path is for the rare "give me everything, ranked" call, 10M vectors sort in a few milliseconds.
+// scores of one query (scan_scores_kernel: the reference-order arithmetic the exact engine uses), then the part of the full
+// sort of (score, index) composites that the truncation keeps: radix select of the k-th + sort of the best k (sort_full.hip;
+// batch.rs:754-763, 790-799, scalar.rs:383-392; for batch_knn's TopK, batch.rs:398-409, the same k smallest in the same order up
+// to ties at equal distances). One query at a time: the path is for the rare "give me everything, ranked" call.
 // metric < 0: u8 codes (aux = per-query sum(q)); cosine: aux = per-query norms.
 static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, size_t D, const float* aux, size_t Q,
                                  size_t kout, uint64_t* d_out_idx, float* d_out_score) {
     innr_ctx* c = b->ctx;
     const size_t ldq = round_up(D ? D : 1, 4), N = b->N;
-    if (N > 0x7fffffffull) {  // rocPRIM's item count is an int
-        set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 vectors per batch (N=%zu)", kout, N);
-        return INNR_E_UNSUPPORTED;
-    }
     size_t tmp_bytes = 0;
     INNR_HIP_CHECK(full_sort_scratch_bytes(N, &tmp_bytes));
     INNR_TRY(c->q_one.ensure(ldq * sizeof(float)));
     INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
-    INNR_TRY(c->sort_keys.ensure(2 * N * sizeof(uint64_t)));
+    INNR_TRY(c->sort_keys.ensure((N + full_topk_out_capacity(kout)) * sizeof(uint64_t)));
     INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
     INNR_HIP_CHECK(hipMemsetAsync(c->q_one.p, 0, ldq * sizeof(float), c->stream));
     if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
@@ -1968,7 +1965,7 @@ static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, siz
                                                                                           b->norms, aux + q, ds, b->ldN);
         }
         INNR_HIP_CHECK(hipGetLastError());
-        INNR_HIP_CHECK(full_sort_scores(ds, N, smaller, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream));
+        INNR_HIP_CHECK(full_sort_scores(ds, N, smaller, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream, nullptr, kout));
         emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(keys + N, 0, 1, (uint32_t)kout, smaller,
                                                                                b->index_base, d_out_idx + q * kout,
                                                                                d_out_score + q * kout);
@@ -3446,17 +3443,13 @@ static innr_status maxsim_topk_exact(innr_docs* d, int cosine, const float* qtok
     INNR_TRY(maxsim_scores_dev(d, cosine, qtok, Tq, d->dim));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     if (kout > INNR_MAX_K) {  // more results than a candidate list holds: sort all document scores (cf. knn_full_sort)
-        if (d->ndocs > 0x7fffffffull) {
-            set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 documents", kout);
-            return INNR_E_UNSUPPORTED;
-        }
         size_t tmp_bytes = 0;
         INNR_HIP_CHECK(full_sort_scratch_bytes(d->ndocs, &tmp_bytes));
-        INNR_TRY(c->sort_keys.ensure(2 * d->ndocs * sizeof(uint64_t)));
+        INNR_TRY(c->sort_keys.ensure((d->ndocs + full_topk_out_capacity(kout)) * sizeof(uint64_t)));
         INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
         uint64_t* keys = c->sort_keys.as<uint64_t>();
         INNR_HIP_CHECK(full_sort_scores(c->scores.as<float>(), d->ndocs, false, keys, keys + d->ndocs, c->sort_tmp.p, tmp_bytes,
-                                        c->stream));
+                                        c->stream, nullptr, kout));
         emit_results_kernel<<<(unsigned)((kout + 255) / 256), 256, 0, c->stream>>>(keys + d->ndocs, 0, 1, (uint32_t)kout, false,
                                                                                d->index_base, c->out_idx.as<uint64_t>() + out_off,
                                                                                c->out_score.as<float>() + out_off);
@@ -3696,15 +3689,11 @@ static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k,
         // caller's dimension order for batch_knn_reordered, batch.rs:640-648), a full sort of (distance, index) with the
         // vectors that do not pass the predicate keyed last (batch.rs:839-849), truncate to min(k, passing).
         const size_t N = b->N, ldq = round_up(D ? D : 1, 4);
-        if (N > 0x7fffffffull) {
-            set_error("k=%zu > INNR_MAX_K needs the full-sort path, which handles at most 2^31 - 1 vectors per batch (N=%zu)", kout, N);
-            return INNR_E_UNSUPPORTED;
-        }
         size_t tmp_bytes = 0, npass = N;
         INNR_HIP_CHECK(full_sort_scratch_bytes(N, &tmp_bytes));
         INNR_TRY(c->q_one.ensure(ldq * sizeof(float)));
         INNR_TRY(c->scores.ensure(b->ldN * sizeof(float)));
-        INNR_TRY(c->sort_keys.ensure(2 * N * sizeof(uint64_t)));
+        INNR_TRY(c->sort_keys.ensure((N + full_topk_out_capacity(kout)) * sizeof(uint64_t)));
         INNR_TRY(c->sort_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
         INNR_HIP_CHECK(hipMemsetAsync(c->q_one.p, 0, ldq * sizeof(float), c->stream));
         if (D) INNR_HIP_CHECK(copy_in(c, c->q_one.p, q, D * sizeof(float)));
@@ -3731,8 +3720,8 @@ static innr_status knn_l2_ext(innr_batch* b, const float* q, size_t D, size_t k,
         }
         INNR_HIP_CHECK(hipGetLastError());
         uint64_t* keys = c->sort_keys.as<uint64_t>();
-        INNR_HIP_CHECK(full_sort_scores(c->scores.as<float>(), N, true, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream, dmask));
         const size_t n = std::min(kout, npass);
+        INNR_HIP_CHECK(full_sort_scores(c->scores.as<float>(), N, true, keys, keys + N, c->sort_tmp.p, tmp_bytes, c->stream, dmask, n));
         if (n) {
             INNR_TRY(c->out_idx.ensure(n * sizeof(uint64_t)));
             INNR_TRY(c->out_score.ensure(n * sizeof(float)));

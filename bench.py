@@ -43,10 +43,15 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
     data = oracle.from_rows(rows)
     del rows
     queries = oracle.generate_uniform(128, dim, 0xBE7C)
-    oracle.batch_knn_dot(queries[0], data[:, :1000].copy(), k)  # warm the library
+    knn = oracle.native_knn_dot()  # the -march=native build made at the start of this run (None: no compiler on this host)
+    flags = "-O3 -march=native -ffp-contract=off (built on this host)" if knn else "-O3 -march=x86-64-v3 -ffp-contract=off (the portable build)"
+    knn = knn or oracle.batch_knn_dot
+    i0, s0 = knn(queries[0], data[:, :1000].copy(), k)  # warm the library; the native build must agree with the checker's
+    i1, s1 = oracle.batch_knn_dot(queries[0], data[:, :1000].copy(), k)
+    assert np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
     done, t0 = 0, time.perf_counter()
     while done < len(queries):
-        oracle.batch_knn_dot(queries[done], data, k)
+        knn(queries[done], data, k)
         done += 1
         if time.perf_counter() - t0 >= budget_s:
             break
@@ -58,7 +63,7 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
         "kind": "port",
         "qps_at_10M": (done / dt) * (n / 10_000_000),
         "sample": f"oracle batch_knn_dot (scan + full stable sort), {done} queries x {n} x {dim} f32 uniform(-1,1), k={k}, "
-                  f"{dt:.1f} s on 1 host thread; the scan is O(N) so vectors/s carries to 10M",
+                  f"{dt:.1f} s on 1 host thread; the scan is O(N) so vectors/s carries to 10M; gcc {flags}",
     }
     # the only parallelism a reference user could add without changing innr: one query per host core
     try:
@@ -66,7 +71,7 @@ def cpu_baseline(dim: int, k: int, budget_s: float = 20.0):
         cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box's CPU share is 16 cores whatever the affinity mask says
         if cores > 1:
             def one(j):
-                oracle.batch_knn_dot(queries[j % len(queries)], data, k)  # ctypes releases the GIL
+                knn(queries[j % len(queries)], data, k)  # ctypes releases the GIL
             t1 = time.perf_counter()
             jobs = 0
             with ThreadPoolExecutor(cores) as ex:
@@ -238,6 +243,7 @@ def main() -> None:
     if not args.no_cpu_baseline and int(os.environ.get("RANK", "0")) == 0:
         import oracle
         oracle.lib()  # load (or, on a stale build, re-make) the CPU checker BEFORE this process touches the GPU: no exec after HIP init
+        oracle.build_native()  # the same source compiled -march=native on THIS host, for the cpu_baseline leg
 
     import torch
     import torch.distributed as dist

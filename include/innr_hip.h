@@ -19,6 +19,12 @@
  *   - indices are reported as uint64 (Rust usize); on device they are u32 (N < 2^32 - 1 per shard)
  *     plus a 64-bit per-shard base (innr_batch_set_index_base) for range-partitioned corpora.
  *   - results are deterministic: same inputs => same bits (tests/integration.rs:134-151).
+ *   - NaN. A NaN in the INPUT keeps its sign through every entry point (total_cmp ranks -NaN below -inf and +NaN above
+ *     +inf, so the sign decides where such a vector lands). A NaN that an invalid operation GENERATES -- inf * 0 in a dot
+ *     product, inf / inf in a cosine -- has the sign the ISA gives it, and the reference inherits its host's: x86 produces
+ *     0xFFC00000 (sign bit set), aarch64 0x7FC00000. gfx950 produces 0xFFC00000 like x86 (measured, tools/nan_probe.py), and this
+ *     ABI guarantees it on every engine: a generated NaN is 0xFFC00000 and ranks LAST in batch_knn_dot / batch_knn_cosine (below
+ *     -inf), as on the reference's x86 hosts (tests/test_gpu_exact.py::test_generated_nan_sign_and_rank_are_pinned).
  *   - there is NO CPU fallback inside this library. If no GPU is present, innr_ctx_create fails.
  */
 #ifndef INNR_HIP_H

@@ -2008,11 +2008,14 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     // for its threshold filter to bite (with a handful of tiles per slice nearly every score is appended)
     if (engine == INNR_KNN_AUTO) {
         engine = innr_batch_auto_engine(b, Q);
-        // A low-precision FILTER (identical results; 6-7x the f32 engine's rate at C2) when one applies -- dot / cosine, k <= 48,
-        // a batch large enough to pay for the extra passes -- and its K-packed corpus copy exists already or fits next to
-        // everything else with room to spare (copies are kept for the batch's lifetime): the int8 one first (N*D bytes, the
-        // faster kernel), else the bf16 one (N*D*2 bytes).
-        if (engine == INNR_KNN_MFMA && Q >= 128 && kout <= INNR_MAX_K && !b->ctx->tune.no_auto_bf16) {
+        // A low-precision FILTER (identical results) when one applies and its K-packed corpus copy exists already or fits next to
+        // everything else with room to spare (copies are kept for the batch's lifetime). Measured at C2 (profiles/r03_midq_*):
+        // the int8 filter (dot / cosine; N*D bytes, a quarter of the f32 corpus to stream) answers 1 .. 128 queries in 3.3 - 4.3 ms
+        // where the exact engine takes 5.2 ms for ONE corpus pass and the f32 GEMM engine 9 - 17 ms: it is the choice for every
+        // batch size once its copy exists, and worth building from 4 queries on; the bf16 filter (squared L2, or when the int8
+        // one is ruled out; N*D*2 bytes) takes 6.0 - 6.7 ms there: from 9 queries on, where the alternative is the f32 GEMM.
+        const bool big_enough = b->N >= 65536 && gemm_addressable(b, Q) && b->gemm_ok;
+        if (big_enough && kout <= INNR_MAX_K && !b->ctx->tune.no_auto_bf16) {
             const bool cosm = metric == INNR_METRIC_COSINE;
             const int bfv = cosm ? kBfCos : (metric == INNR_METRIC_L2SQ ? kBfL2 : kBfDot);
             size_t free_b = 0, total_b = 0;
@@ -2020,11 +2023,12 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
             const size_t slack = (size_t)8 << 30;
             // (a corpus marked weak -- its proofs failed on the int8 filter -- is looked at again every 64th call: data change)
             const bool weak = (cosm ? b->i8n_weak : b->i8_weak) && (++b->i8_weak_skips % 64u) != 0;
+            const bool i8_copy = (cosm ? b->Ai8n : b->Ai8) != nullptr;
             if (f32_i8_eligible(b, metric, Q, kout) && !b->ctx->tune.no_auto_i8 && !weak &&
-                ((cosm ? b->Ai8n : b->Ai8) != nullptr || (have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
+                (i8_copy || (Q >= 4 && have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
                 engine = INNR_KNN_MFMA_I8;
-            else if ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
-                     (have_mem && free_b > 2 * bf16_copy_bytes(b, bfv) + slack))
+            else if (Q >= 9 && ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
+                                (have_mem && free_b > 2 * bf16_copy_bytes(b, bfv) + slack)))
                 engine = INNR_KNN_MFMA_BF16;
         }
     }
@@ -2881,7 +2885,8 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     // the reference's own accumulation against the true dot: (D + 2) u |q||v| (half of the f32 GEMM engine's cdu)
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
     f32i8_finish_bound_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, c->stream>>>(qc, (uint32_t)p.Qpad, (uint32_t)Q, ql1, c->q_norm.as<float>(),
-                                                                               alpha, cos ? cdu * 1.02f : cdu * b->max_norm, cos ? 1 : 0);
+                                                                               alpha, cos ? cdu * 1.02f : cdu * b->max_norm, cos ? 1 : 0,
+                                                                               128.0f * alpha / 255.0f + offset, (float)b->D);
     INNR_HIP_CHECK(hipGetLastError());
     const float* eq = qc + 3 * p.Qpad;
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));

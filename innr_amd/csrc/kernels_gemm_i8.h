@@ -155,12 +155,17 @@ __global__ void f32i8_query_prep_kernel(const float* __restrict__ Qm, uint32_t Q
 
 // the proof's bound per query: the int8 engine's own share (qc[3]: the query's quantisation, float rounding) + the corpus
 // quantisation (alpha / 510 per value, clamp slack) + the reference's own f32 accumulation against the true dot
+// centre = 128 alpha/255 + offset multiplies the query's SUM in B_j; that sum is accumulated in f32 (f32i8_query_prep_kernel), off
+// the true one by up to (D - 1) u |q|_1 -- nothing for a corpus centred on zero, the dominant term for an off-centre range (ReLU
+// embeddings, tf-idf in [0, 1]: |centre| / alpha = 1/2)
 __global__ void f32i8_finish_bound_kernel(float* __restrict__ qc, uint32_t Qpad, uint32_t Q, const float* __restrict__ ql1,
-                                          const float* __restrict__ qnorm, float alpha, float ref_scale, int cosine) {
+                                          const float* __restrict__ qnorm, float alpha, float ref_scale, int cosine, float centre,
+                                          float D) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Q) return;
     const float ref = cosine ? ref_scale : ref_scale * qnorm[j];
-    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + (alpha / 510.0f) * 1.002f * ql1[j] + ref) * 1.0001f;
+    const float sum_err = fabsf(centre) * D * 6.0e-8f * ql1[j];
+    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + (alpha / 510.0f) * 1.002f * ql1[j] + sum_err + ref) * 1.0001f;
 }
 
 __global__ void seed_thresholds_eq_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
@@ -634,7 +639,9 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     s.cnt[threadIdx.x] = 0;  // kI8hBQ == threads
     s.thr[threadIdx.x] = 0;
     uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
-
+    // (Tried: waves whose 64 queries are all padding skip their fragment loads, MFMAs and epilogue -- a batch smaller than the tile
+    //  pays the MFMA work of 512 queries, 59 % of the int8 pipe on padding at one query. The wave-uniform branch around the K-step
+    //  made the compiled loop slower for EVERY batch size: 2.67 -> 3.05 ms at 1 query, 4.20 -> 5.17 at 512; not kept.)
     i32x16_t acc[4][2];  // [row tile][query column tile]: the HIGH limb's sums
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)

@@ -38,6 +38,28 @@ def build(force: bool = False) -> str:
 
 
 _lib: Optional[C.CDLL] = None
+_NATIVE_SO = os.path.join(_HERE, "_build", "libinnr_oracle_native.so")
+
+
+def build_native() -> Optional[str]:
+    """The oracle compiled -march=native ON THIS HOST (bench.py's cpu_baseline leg). Returns the path, or
+    None if it cannot be built here (no gcc / make). Call it before the process initialises the GPU: it starts a child."""
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])  # -B: always for THIS host, never a copy from another
+        return _NATIVE_SO
+    except Exception:
+        return None
+
+
+def native_knn_dot():
+    """batch_knn_dot of the -march=native build (None if build_native() has not produced it)"""
+    if not os.path.exists(_NATIVE_SO):
+        return None
+    L = C.CDLL(_NATIVE_SO)
+    f = L.orc_batch_knn_dot
+    f.restype = _sz
+    f.argtypes = [_f32p, _f32p, _sz, _sz, _sz, _u64p, _f32p]
+    return lambda q, data, k: _knn(f, q, data, k)
 
 
 def lib() -> C.CDLL:

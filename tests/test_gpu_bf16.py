@@ -155,3 +155,26 @@ def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     _check_knn(B, innr, "cos", z, oracle.from_rows(z), qz, 10, innr.KNN_MFMA_I8)
     lrows, ldata = _corpus(70_000, 128, 0)  # the reference example's LCG data: proofs fail, results must not
     _check_knn(B, innr, "dot", lrows, ldata, _queries(24, 128), 10, innr.KNN_MFMA_I8)
+
+
+def test_int8_filter_off_centre_range_and_extreme_thresholds(B, innr):
+    """(1) a corpus whose range is far from zero (values in [0, 1]: ReLU embeddings, tf-idf) with equal-magnitude
+    queries -- the query SUM that multiplies the range centre is accumulated in f32, and its error belongs in the proof's bound;
+    (2) thresholds in the top band of the integer domain (D = 768, a constant negative query against near-minimum rows with
+    distinct scores): the integer threshold must saturate only at the real limit of V. Answers: the exact engine's."""
+    rng = np.random.default_rng(77)
+    rows = rng.uniform(0.0, 1.0, size=(60_000, 768)).astype(np.float32)
+    vb = B.VerticalBatch.from_rows(rows)
+    qs = np.where(rng.uniform(size=(160, 768)) < 0.5, np.float32(-1.0), np.float32(1.0)).astype(np.float32)
+    qs[1] = 1.0  # the largest possible |sum|
+    qs[2] = -1.0  # a constant negative query: the best rows are the near-minimum ones
+    rows2 = rows.copy()
+    rows2[:300] = (np.arange(300, dtype=np.float32)[:, None] * np.float32(1e-6)) + np.float32(1e-4)  # > 256 near-minimum rows, distinct scores
+    vb2 = B.VerticalBatch.from_rows(rows2)
+    for batch, k in ((vb, 10), (vb2, 32), (vb2, 10)):
+        for fn in (B.batch_knn_dot_multi, B.batch_knn_cosine_multi):
+            st = innr.KnnStats()
+            i1, s1 = fn(qs, batch, k, engine=innr.KNN_MFMA_I8, stats=st)
+            assert st.engine == innr.KNN_MFMA_I8
+            i0, s0 = fn(qs[:24], batch, k, engine=innr.KNN_EXACT)
+            assert np.array_equal(i1[:24], i0) and bits_equal(s1[:24], s0)

@@ -274,6 +274,31 @@ def test_knn_nan_inf_ordering(B, innr):
     _check_knn(B, innr, "cos", rows, oracle.from_rows(rows), q.reshape(1, -1), 5, innr.KNN_EXACT)
 
 
+def test_generated_nan_sign_and_rank_are_pinned(B, innr):
+    """A NaN that an invalid operation GENERATES (inf * 0 under dot, inf / inf under cosine) has an ISA-defined sign. Measured on
+    gfx950 (tools/nan_probe.py): 0xFFC00000, the default NaN with the sign bit SET -- the same pattern the reference's usual x86
+    hosts produce -- which total_cmp ranks below -inf: LAST in batch_knn_dot / batch_knn_cosine's descending order. include/innr_hip.h states
+    this as the ABI's guarantee; pinned here on every engine, together with equality to the oracle (an x86 host)."""
+    rows = oracle.generate_uniform(4000, 16, 3)
+    rows[1234, 5] = np.inf
+    q = oracle.generate_uniform(1, 16, 8)[0]
+    q[5] = 0.0  # inf * 0
+    q2 = oracle.generate_uniform(1, 16, 9)[0]  # cosine: the row's norm is +inf and its dot product +-inf: inf / inf
+    data = oracle.from_rows(rows)
+    vb = B.VerticalBatch.from_rows(rows)
+    assert B.batch_dot(q, vb)[1234:1235].view(np.uint32)[0] == 0xFFC00000
+    assert B.batch_cosine(q2, vb, B.batch_norms(vb))[1234:1235].view(np.uint32)[0] == 0xFFC00000
+    for engine in (innr.KNN_EXACT, innr.KNN_MFMA):
+        idx, sc = B.batch_knn_dot_multi(q.reshape(1, -1), vb, 4000, engine=engine)
+        assert idx[0][-1] == 1234 and sc[0][-1:].view(np.uint32)[0] == 0xFFC00000, (engine, idx[0][-3:], sc[0][-3:].view(np.uint32))
+        idx, sc = B.batch_knn_cosine_multi(q2.reshape(1, -1), vb, 4000, engine=engine)
+        assert idx[0][-1] == 1234 and sc[0][-1:].view(np.uint32)[0] == 0xFFC00000, (engine, idx[0][-3:], sc[0][-3:].view(np.uint32))
+        _check_knn(B, innr, "dot", vb, data, q.reshape(1, -1), 6, engine)      # the top of the list: untouched by it
+        _check_knn(B, innr, "cos", vb, data, q2.reshape(1, -1), 6, engine)
+    oi, os_ = oracle.batch_knn_dot(q, data, 4000)  # the oracle on this (x86) host: the same bits at the same place
+    assert int(oi[-1]) == 1234 and os_[-1:].view(np.uint32)[0] == 0xFFC00000
+
+
 def test_knn_monotone_scores_force_many_compactions(B, innr):
     # scores increase with the index: every vector beats the running threshold, so candidate lists fill and
     # compact over and over (the worst case of the threshold filter).
@@ -304,7 +329,8 @@ def test_backend_introspection(B, innr):
     assert BK.batch_backend(big, 100) == BK.Backend.HIP_MFMA and str(BK.dense_backend(768)) == "portable"
     st = innr.KnnStats()
     B.batch_knn_dot_multi(oracle.generate_uniform(100, 16, 1), big, 3, stats=st)
-    assert st.engine == innr.KNN_MFMA and "gfx950" in BK.version()
+    # a matrix-pipe engine: the int8 filter when its corpus copy fits (what AUTO prefers at every batch size from 4 queries on)
+    assert st.engine in (innr.KNN_MFMA, innr.KNN_MFMA_I8, innr.KNN_MFMA_BF16) and "gfx950" in BK.version()
 
 
 def test_save_load_roundtrip(B, tmp_path):

@@ -169,14 +169,31 @@ def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
 
 
 def test_knn_auto_engine_selection(B, innr):
+    """INNR_KNN_AUTO (api.hip, innr_batch_knn_dev): up to 3 queries the exact engine (one HBM-bound corpus pass, no extra memory);
+    from 4 queries on the int8 filter for dot / cosine when its corpus copy fits -- and for EVERY batch size once it exists --,
+    the bf16 filter for squared L2 from 9 queries on; a corpus of a few tiles per slice stays on the exact engine."""
     vb = B.VerticalBatch.generate(100_000, 64, 0)
     st = innr.KnnStats()
-    B.batch_knn_dot_multi(_queries(4, 64, uniform=True), vb, 5, stats=st)
+    B.batch_knn_dot_multi(_queries(3, 64, uniform=True), vb, 5, stats=st)
     assert st.engine == innr.KNN_EXACT
+    i4, s4 = B.batch_knn_dot_multi(_queries(4, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8
+    e4, es4 = B.batch_knn_dot_multi(_queries(4, 64, uniform=True), vb, 5, engine=innr.KNN_EXACT)
+    assert np.array_equal(i4, e4) and bits_equal(s4, es4)
+    i1, s1 = B.batch_knn_dot_multi(_queries(1, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8  # the copy exists now: one query too
+    e1, es1 = B.batch_knn_dot_multi(_queries(1, 64, uniform=True), vb, 5, engine=innr.KNN_EXACT)
+    assert np.array_equal(i1, e1) and bits_equal(s1, es1)
     B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
-    assert st.engine == innr.KNN_MFMA
+    assert st.engine == innr.KNN_MFMA_I8
+    B.batch_knn_multi(_queries(8, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_EXACT  # squared L2, 8 queries: one exact pass
     B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
-    assert st.engine == innr.KNN_MFMA and st.queries_fallback <= 1
+    assert st.engine == innr.KNN_MFMA_BF16 and st.queries_fallback <= 1
+    from innr_amd import _lib
+    with _lib.default_context().option("no_auto_bf16", 1):  # no low-precision filter at all: the f32 GEMM engine
+        B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
+        assert st.engine == innr.KNN_MFMA
     small = B.VerticalBatch.generate(3000, 64, 0)  # a few tiles per slice: the exact engine, all query groups in one launch
     B.batch_knn_dot_multi(_queries(64, 64, uniform=True), small, 5, stats=st)
     assert st.engine == innr.KNN_EXACT

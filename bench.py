@@ -93,7 +93,7 @@ def pmc_traffic(args):
     section HBM; calibrated here on norms_kernel: 1.50e7 KB reported for a 30.72 GB read)."""
     default = (args.n_per_gpu, args.dim, args.queries, args.k, args.metric) == (10_000_000, 768, 1024, 10, "dot")
     vals = {}
-    rnd = next((r for r in ("r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_bench_n1_pmc_FETCH_SIZE.csv"))), "r01")
+    rnd = next((r for r in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_bench_n1_pmc_FETCH_SIZE.csv"))), "r01")
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_bench_n1_pmc_{name}.csv")
         if not default or not os.path.exists(path):

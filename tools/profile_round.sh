@@ -6,7 +6,7 @@
 # Afterwards copy the summaries into profiles/ (tools/pmc_summary.py writes them in the committed format).
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
 echo "bench done"

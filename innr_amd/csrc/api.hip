@@ -90,6 +90,7 @@ struct innr_tuning {
     long no_completion = 0;      // unproven queries of the f32 engine: straight to the KP retry / exact engine (no completion pass)
     long trace = 0;              // diagnostics of the redo paths on stderr (list lengths of the completion pass, ...)
     long no_rows_copy = 0;       // never build the row-major copy: the completion pass re-scores by column gathers (what a full HBM does)
+    long i8_slices_per_cu = 0;   // corpus slices (= blocks) per CU and query tile of the int8 filters; 0 = by metric (plan_i8)
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -100,6 +101,7 @@ static const TuneName kTuneNames[] = {
     {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
     {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
+    {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -240,6 +242,12 @@ struct innr_batch {
     // normalised rows quantised over [-1, 1] (Ai8n: the cosine filter) -- INNR_KNN_MFMA_I8 on an f32 batch
     char* Ai8n = nullptr;
     float i8_alpha = 0.0f, i8_offset = 0.0f, i8n_alpha = 0.0f, i8n_offset = 0.0f;
+    // ... and the squared-L2 copy: the dot copy's quantisation plus R + 1 more dimensions that carry |v|^2 in two 8-bit limbs
+    // (pack_corpus_f32_i8_kernel); D' = D + R + 1, ai8l_nk K-steps
+    char* Ai8l = nullptr;
+    uint32_t ai8l_nk = 0, i8l_R = 0;
+    float i8l_nmax = 0.0f;
+    bool i8l_weak = false;
     bool i8_weak = false, i8n_weak = false;  // most proofs failed on this corpus (a range blown up by outliers): AUTO stops picking the filter
     uint32_t i8_weak_skips = 0;              // AUTO calls that skipped the int8 filter since (every 64th tries it again)
 };
@@ -1367,7 +1375,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
 // visits its append path -- what the K-loop and the fast reject cost alone. Such a call fills its stats and then FAILS: a timing
 // run must not hand out results.
 static constexpr bool i8h_probe_skips_visits() {
-    return (kI8hProbe & (1 | 8 | 16 | 32)) != 0;  // (8, 16: the K-loop fed from L1 / L2 instead of its real operands)
+    return (kI8hProbe & (1 | 8 | 16 | 32 | 64 | 128)) != 0;  // (8, 16: the K-loop fed from L1 / L2 instead of its real operands)
 }
 
 static innr_status check_errflag(innr_ctx* c) {
@@ -1375,14 +1383,22 @@ static innr_status check_errflag(innr_ctx* c) {
     INNR_HIP_CHECK(copy_out(c, &e, c->flags.p, sizeof(e)));
     INNR_HIP_CHECK(ctx_sync(c));
     if constexpr ((kI8hProbe & 4) != 0) {  // tools/i8h_probe.py: the one-limb int8 kernel's visit counters
-        uint32_t h[18] = {0};
+        uint32_t h[24] = {0};
         INNR_HIP_CHECK(hipMemcpyAsync(h, c->flags.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
-        unsigned long long cv, cs, ct;
-        memcpy(&cv, h + 12, 8); memcpy(&cs, h + 14, 8); memcpy(&ct, h + 16, 8);
+        unsigned long long cv, cs, ct, cq;
+        memcpy(&cv, h + 12, 8); memcpy(&cs, h + 14, 8); memcpy(&ct, h + 16, 8); memcpy(&cq, h + 20, 8);
         fprintf(stderr, "i8h probe: wave epilogues that visit %u | survivors of the coarse test %u | bound re-derivations %u | cycles per "
-                "visit %.0f, of them in the survivors' loops %.0f, publish + compaction %.0f\n", h[8], h[9], h[10],
-                h[8] ? (double)cv / h[8] : 0.0, h[8] ? (double)cs / h[8] : 0.0, h[8] ? (double)ct / h[8] : 0.0);
+                "visit %.0f, of them in the survivors' loops %.0f, publish + compaction %.0f | appended %u (summed over lanes) | wave epilogues "
+                "with a hit %u, cycles queueing each %.0f | longest wave %.0f cycles, shortest %.0f\n", h[8], h[9], h[10],
+                h[8] ? (double)cv / h[8] : 0.0, h[8] ? (double)cs / h[8] : 0.0, h[8] ? (double)ct / h[8] : 0.0, h[11], h[18],
+                h[18] ? (double)cq / h[18] : 0.0, 16.0 * h[22], 16.0 * (double)(~h[23]));
+        uint32_t hb[512] = {0};
+        INNR_HIP_CHECK(hipMemcpyAsync(hb, c->flags.as<uint32_t>() + 128, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+        INNR_HIP_CHECK(hipStreamSynchronize(c->stream));
+        fprintf(stderr, "i8h probe: Mcycles per block:");
+        for (int i = 0; i < 512 && hb[i]; ++i) fprintf(stderr, "%s%.1f", i % 32 ? " " : "\n  ", 16e-6 * hb[i]);
+        fprintf(stderr, "\n");
     }
     if (e) {
         set_error("internal: candidate-list invariant violated (flag=%u)", e);
@@ -1617,6 +1633,7 @@ void innr_batch_free(innr_batch* b) {
     if (b->Abl) (void)hipFree(b->Abl);
     if (b->Ai8) (void)hipFree(b->Ai8);
     if (b->Ai8n) (void)hipFree(b->Ai8n);
+    if (b->Ai8l) (void)hipFree(b->Ai8l);
     delete b;
 }
 
@@ -1976,7 +1993,7 @@ static innr_status knn_full_sort(innr_batch* b, int metric, const float* dQ, siz
 
 // the int8 filter in front of an f32 corpus (defined with the int8 engine further down)
 static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout);
-static size_t f32_i8_copy_bytes(const innr_batch* b);
+static size_t f32_i8_copy_bytes(const innr_batch* b, int metric);
 
 
 extern "C" {
@@ -2022,18 +2039,19 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
             const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
             const size_t slack = (size_t)8 << 30;
             // (a corpus marked weak -- its proofs failed on the int8 filter -- is looked at again every 64th call: data change)
-            const bool weak = (cosm ? b->i8n_weak : b->i8_weak) && (++b->i8_weak_skips % 64u) != 0;
-            const bool i8_copy = (cosm ? b->Ai8n : b->Ai8) != nullptr;
+            const bool l2m = metric == INNR_METRIC_L2SQ;
+            const bool weak = (cosm ? b->i8n_weak : (l2m ? b->i8l_weak : b->i8_weak)) && (++b->i8_weak_skips % 64u) != 0;
+            const bool i8_copy = (cosm ? b->Ai8n : (l2m ? b->Ai8l : b->Ai8)) != nullptr;
             if (f32_i8_eligible(b, metric, Q, kout) && !b->ctx->tune.no_auto_i8 && !weak &&
-                (i8_copy || (Q >= 4 && have_mem && free_b > 2 * f32_i8_copy_bytes(b) + slack)))
+                (i8_copy || (Q >= 4 && have_mem && free_b > 2 * f32_i8_copy_bytes(b, metric) + slack)))
                 engine = INNR_KNN_MFMA_I8;
             else if (Q >= 9 && ((bfv == kBfCos ? b->Abn : (bfv == kBfL2 ? b->Abl : b->Ab)) != nullptr ||
                                 (have_mem && free_b > 2 * bf16_copy_bytes(b, bfv) + slack)))
                 engine = INNR_KNN_MFMA_BF16;
         }
     }
-    if (engine == INNR_KNN_MFMA_I8 && !f32_i8_eligible(b, metric, Q, kout))  // squared L2 (the bf16 filter has it), k > 48, a view ...
-        engine = metric == INNR_METRIC_L2SQ ? INNR_KNN_MFMA_BF16 : INNR_KNN_MFMA;
+    if (engine == INNR_KNN_MFMA_I8 && !f32_i8_eligible(b, metric, Q, kout))  // k > 240, a view, a u8 batch ...
+        engine = INNR_KNN_MFMA;
     if ((engine == INNR_KNN_MFMA || engine == INNR_KNN_MFMA_BF16 || engine == INNR_KNN_MFMA_I8) && !gemm_addressable(b, Q)) engine = INNR_KNN_EXACT;
     if (kout > INNR_MAX_K) engine = INNR_KNN_EXACT;  // the full-sort path below: exact by construction
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
@@ -2269,7 +2287,7 @@ innr_status innr_batch_minmax(innr_batch* b, float* out_min, float* out_max, int
     if (b->N == 0 || b->D == 0) return INNR_OK;
     INNR_TRY(c->misc.ensure(4096));
     INNR_HIP_CHECK(hipMemsetAsync(c->misc.p, 0, 8, c->stream));
-    dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+    dim3 grid((unsigned)std::min<size_t>((b->ldN / 4 + 255) / 256, 256), (unsigned)std::min<size_t>(b->D, 32));  // <= 8192 blocks, one atomic pair each
     minmax_pdx_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, c->misc.as<uint32_t>());
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t k[2] = {0, 0};
@@ -2304,7 +2322,7 @@ innr_status innr_batch_quantile_range(innr_batch* b, float quantile, float* out_
     if (b->N == 0 || b->D == 0) return INNR_OK;
     INNR_TRY(c->misc.ensure(512 * sizeof(unsigned long long)));
     unsigned long long* dh = c->misc.as<unsigned long long>();
-    dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+    dim3 grid((unsigned)std::min<size_t>((b->ldN / 4 + 255) / 256, 256), (unsigned)std::min<size_t>(b->D, 32));  // <= 8192 blocks, one atomic pair each
     unsigned long long hist[512];
     uint32_t pref[2] = {0u, 0u};
     unsigned long long rank[2] = {0ull, 0ull};
@@ -2609,18 +2627,21 @@ static innr_status ensure_i8_corpus(innr_batch* b) {
 struct I8Plan {
     size_t Qpad;
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
+    uint32_t nk;  // K-steps of 64 dimensions of the corpus copy the launch multiplies (the squared-L2 copy has more than the others)
     bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
 };
 static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0, bool one_limb = false) {
     I8Plan p;
     p.two = !one_limb && (i8_two_limb(b->ctx, kout) || kp_override > 128);  // (collect mode: always the one-limb kernel)
+    p.nk = b->ai8_nk ? b->ai8_nk : i8_nk(b);
     const size_t bq = p.two ? (size_t)kI8BQ : (size_t)kI8hBQ;  // queries per block tile
     p.Qpad = round_up(Q, bq);
     p.nqt = (uint32_t)(p.Qpad / bq);
     p.KP = kp_override ? kp_override : pick_kp(kout, 16);
     p.cap = (uint32_t)cand_cap((int)p.KP);
     p.ntiles = (uint32_t)(b->ldN / 128);
-    const uint32_t target = std::max(1u, (uint32_t)b->ctx->num_cus / p.nqt);  // one 8-wave block per CU
+    uint32_t target = std::max(1u, (uint32_t)b->ctx->num_cus / p.nqt);  // one 8-wave block per CU
+    if (const long v = b->ctx->tune.i8_slices_per_cu; v > 1) target *= (uint32_t)std::min<long>(v, 16);
     uint32_t ns = std::max(8u, target / 8 * 8);
     ns = std::min(ns, (uint32_t)round_up(p.ntiles, 8));
     p.nslices = ns;
@@ -2647,7 +2668,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     INNR_TRY(prep_gthr(c, p.Qpad, MODE == 2 ? 32u : p.KP, seed, nreal_q, kmargin, &gslots, &nslot));  // (MODE 2: only the bounds are used)
     const bool two = p.two;
 #define INNR_I8_ARGS                                                                                                      \
-    corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, b->ai8_nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
+    corpus, c->q_bf16.as<char>(), p.ntiles, (uint32_t)b->N, p.nk, p.Qpad, p.nqt, p.qtg, p.tps, qc, c->lists.as<uint64_t>(), \
         c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot, dump, ld_dump
 #define INNR_I8_LAUNCH(RR)                                                                                                \
     do {                                                                                                                  \
@@ -2677,12 +2698,13 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
 // queries -> two int8 limbs + per-query constants: Bq in c->q_bf16, qc[5][Qpad] at c->misc
 // (alpha, offset: the code corpus' QuantizationParams, or the scalar quantisation of an f32 corpus' filter copy)
 static innr_status prep_queries_i8(innr_batch* b, const I8Plan& p, const float* dQ, size_t Q, const float* qsum, float alpha,
-                                   float offset) {
+                                   float offset, size_t Dq = 0 /* query dimension if not the batch's (the squared-L2 copy's D') */) {
     innr_ctx* c = b->ctx;
-    INNR_TRY(c->q_bf16.ensure((size_t)b->ai8_nk * 8 * p.Qpad * 16));
+    if (!Dq) Dq = b->D;
+    INNR_TRY(c->q_bf16.ensure((size_t)p.nk * 8 * p.Qpad * 16));
     INNR_TRY(c->misc.ensure(5 * p.Qpad * sizeof(float) + Q * sizeof(uint32_t) + 64));
-    pack_queries_i8_kernel<<<(unsigned)p.Qpad, 64, 0, c->stream>>>(dQ, qsum, (uint32_t)Q, (uint32_t)b->D, b->ai8_nk, (uint32_t)p.Qpad,
-                                                                   i8_limb_r1((uint32_t)b->D, i8_shift(p.two)), i8_shift(p.two), alpha / 255.0f,
+    pack_queries_i8_kernel<<<(unsigned)p.Qpad, 64, 0, c->stream>>>(dQ, qsum, (uint32_t)Q, (uint32_t)Dq, p.nk, (uint32_t)p.Qpad,
+                                                                   i8_limb_r1((uint32_t)Dq, i8_shift(p.two)), i8_shift(p.two), alpha / 255.0f,
                                                                    offset, reinterpret_cast<uint4*>(c->q_bf16.p), c->misc.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     return INNR_OK;
@@ -2787,24 +2809,30 @@ extern "C" innr_status innrdbg_i8_scores(innr_batch* b, const float* queries, si
 // is PROVEN against bound = query quantisation + (alpha / 510) |q|_1 + the reference's own accumulation error; unproven queries
 // go through the f32 GEMM engine as one batch, like the bf16 filter's.
 static bool f32_i8_eligible(const innr_batch* b, int metric, size_t Q, size_t kout) {
-    return b->V && metric != INNR_METRIC_L2SQ && kout <= INNR_MAX_K && b->D >= 1 && b->D <= 65535 &&
-           i8_limb_r1((uint32_t)b->D, 8) >= 1 && i8_limb_r1((uint32_t)b->D, (uint32_t)kI8hS) >= 1 && b->ldN < ((size_t)1 << 31) &&
+    const uint32_t Dx = (uint32_t)b->D + (metric == INNR_METRIC_L2SQ ? 121u : 0u);  // squared L2: up to 121 more dimensions (|v|^2)
+    return b->V && kout <= INNR_MAX_K && b->D >= 1 && Dx <= 65535 &&
+           i8_limb_r1(Dx, 8) >= 1 && i8_limb_r1(Dx, (uint32_t)kI8hS) >= 1 && b->ldN < ((size_t)1 << 31) &&
            Q < ((size_t)1 << 24) && b->gemm_ok;
 }
-static size_t f32_i8_copy_bytes(const innr_batch* b) { return (b->ldN / 128) * (size_t)i8_nk(b) * kI8StageBytes; }
+static size_t f32_i8_copy_bytes(const innr_batch* b, int metric) {  // (squared L2: at most 121 more dimensions)
+    const size_t nk = metric == INNR_METRIC_L2SQ ? round_up(b->D + 121, 128) / 64 : (size_t)i8_nk(b);
+    return (b->ldN / 128) * nk * kI8StageBytes;
+}
 
-static innr_status ensure_f32_i8_corpus(innr_batch* b, bool normalised, bool* usable) {
+enum { kI8Dot = 0, kI8Cos = 1, kI8L2 = 2 };  // which int8 copy of an f32 corpus a call filters on
+static innr_status ensure_f32_i8_corpus(innr_batch* b, int variant, bool* usable) {
     *usable = true;
-    char*& copy = normalised ? b->Ai8n : b->Ai8;
+    const bool normalised = variant == kI8Cos;
+    char*& copy = variant == kI8Cos ? b->Ai8n : (variant == kI8L2 ? b->Ai8l : b->Ai8);
     if (copy) return INNR_OK;
-    // the range of what is quantised: the corpus values, resp. the normalised rows (for 768-dimensional uniform data these live
-    // in +-0.06: quantising them over [-1, 1] would throw four of the eight bits away)
-    float offset, alpha;
-    {
+    // the range of what is quantised: the corpus values (dot and squared L2), resp. the normalised rows (for 768-dimensional
+    // uniform data these live in +-0.06: quantising them over [-1, 1] would throw four of the eight bits away)
+    float offset = normalised ? b->i8n_offset : b->i8_offset, alpha = normalised ? b->i8n_alpha : b->i8_alpha;
+    if (!(alpha > 0.0f)) {
         innr_ctx* c = b->ctx;
         INNR_TRY(c->misc.ensure(4096));
         INNR_HIP_CHECK(hipMemsetAsync(c->misc.p, 0, 8, c->stream));
-        dim3 grid((unsigned)((b->ldN / 4 + 255) / 256), (unsigned)std::min<size_t>(b->D, 64));
+        dim3 grid((unsigned)std::min<size_t>((b->ldN / 4 + 255) / 256, 256), (unsigned)std::min<size_t>(b->D, 32));  // <= 8192 blocks, one atomic pair each
         minmax_pdx_kernel<<<grid, 256, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, c->misc.as<uint32_t>(),
                                                        normalised ? b->invn : nullptr);
         INNR_HIP_CHECK(hipGetLastError());
@@ -2821,7 +2849,19 @@ static innr_status ensure_f32_i8_corpus(innr_batch* b, bool normalised, bool* us
         (normalised ? b->i8n_alpha : b->i8_alpha) = alpha;
         (normalised ? b->i8n_offset : b->i8_offset) = offset;
     }
-    const uint32_t nk = i8_nk(b);
+    uint32_t nk = i8_nk(b), R = 0;
+    float nmax = 0.0f;
+    if (variant == kI8L2) {
+        // |v|^2 in R + 1 more dimensions: R such that the weight -(nmax / alpha) / R of each stays near the 2 q_d beside it
+        nmax = b->max_norm * b->max_norm * 1.000001f;
+        const float ratio = nmax / alpha;
+        if (!(nmax > 0.0f) || !(ratio - ratio == 0.0f)) {
+            *usable = false;
+            return INNR_OK;
+        }
+        R = (uint32_t)std::min(120.0f, std::max(1.0f, ceilf(0.5f * ratio)));
+        nk = (uint32_t)(round_up(b->D + R + 1, 128) / 64);
+    }
     const size_t ntiles = b->ldN / 128, bytes = ntiles * nk * (size_t)kI8StageBytes;
     hipError_t e = hipMalloc((void**)&copy, bytes);
     if (e != hipSuccess) {
@@ -2832,9 +2872,15 @@ static innr_status ensure_f32_i8_corpus(innr_batch* b, bool normalised, bool* us
     const size_t nthreads = ntiles * nk * 128;
     pack_corpus_f32_i8_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, b->ctx->stream>>>(
         b->V, b->ldN, (uint32_t)b->N, (uint32_t)b->D, nk, nthreads, offset, 255.0f / alpha, normalised ? b->invn : nullptr,
-        reinterpret_cast<uint4*>(copy));
+        reinterpret_cast<uint4*>(copy), variant == kI8L2 ? b->sqn : nullptr, R, variant == kI8L2 ? 1.0f / nmax : 0.0f);
     INNR_HIP_CHECK(hipGetLastError());
-    b->ai8_nk = nk;
+    if (variant == kI8L2) {
+        b->ai8l_nk = nk;
+        b->i8l_R = R;
+        b->i8l_nmax = nmax;
+    } else {
+        b->ai8_nk = nk;
+    }
     return INNR_OK;
 }
 
@@ -2847,27 +2893,35 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
                              float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms, bool* served,
                              const float* collect_kth, uint32_t* d_unresolved) {
     innr_ctx* c = b->ctx;
-    const bool cos = metric == INNR_METRIC_COSINE;
+    const bool cos = metric == INNR_METRIC_COSINE, l2 = metric == INNR_METRIC_L2SQ;
     *served = false;
     INNR_TRY(ensure_norms(b));
-    if (!(b->max_norm - b->max_norm == 0.0f) || !(b->max_norm >= 1e-12f)) return INNR_OK;
+    if (!(b->max_norm - b->max_norm == 0.0f) || !(b->max_norm >= 1e-12f) || (l2 && !(b->max_norm <= 1e15f))) return INNR_OK;
     if (cos) INNR_TRY(ensure_invnorms(b));
+    if (l2) INNR_TRY(ensure_sqnorms(b));
     bool usable = true;
-    INNR_TRY(ensure_f32_i8_corpus(b, cos, &usable));
+    INNR_TRY(ensure_f32_i8_corpus(b, cos ? kI8Cos : (l2 ? kI8L2 : kI8Dot), &usable));
     if (!usable) return INNR_OK;
     *served = true;
     const float alpha = cos ? b->i8n_alpha : b->i8_alpha, offset = cos ? b->i8n_offset : b->i8_offset;
+    const char* copy = cos ? b->Ai8n : (l2 ? b->Ai8l : b->Ai8);
+    // squared L2 (pack_corpus_f32_i8_kernel): a dot product over D' = D + R + 1 dimensions plus per-query constants
+    const size_t Dq = l2 ? b->D + b->i8l_R + 1 : b->D;
     // Lists of 4k + 64 let the k-th exact score clear the KP-th approximate one by a visible margin (k <= 48); beyond that the
     // lists hold k + 16 (one-limb kernel up to 128, two-limb kernel to 256), most proofs fail BY DESIGN and the completion pass
     // (one more pass of this filter in collect mode) settles them: k = 100 at C2 needs ~450 candidates per query.
     const bool direct = pick_kp(4 * kout + 64, 0) <= 256;
-    const I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? pick_kp(4 * kout + 64, 0) : pick_kp(kout, 16)), collect_kth != nullptr);
+    I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? pick_kp(4 * kout + 64, 0) : pick_kp(kout, 16)), collect_kth != nullptr);
+    if (l2) p.nk = b->ai8l_nk;
     // exact query norms; cosine: 1/||q|| and the normalised copy the filter multiplies; sum and L1 norm of what it multiplies
     INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
-    INNR_TRY(c->tmp_norms.ensure(3 * p.Qpad * sizeof(float)));
+    INNR_TRY(c->tmp_norms.ensure(6 * p.Qpad * sizeof(float)));
     float* qsum = c->tmp_norms.as<float>();
     float* ql1 = qsum + p.Qpad;
     float* invq = ql1 + p.Qpad;
+    float* cq = invq + p.Qpad;  // squared L2: C_j - |q_j|^2, C_j = (|q_j| + max|v|)^2 (the score space C_j - distance of the f32 engine)
+    float* Cj = cq + p.Qpad;
+    float* ql1q = Cj + p.Qpad;  // ... and the L1 norm of the query itself
     query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     const float* Qp = dQ;
@@ -2877,17 +2931,41 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
         INNR_HIP_CHECK(hipGetLastError());
         Qp = c->q_hat.as<float>();
     }
-    f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, cos ? invq : nullptr,
+    const float W = l2 ? b->i8l_nmax / alpha : 0.0f, w1 = l2 ? W / (float)b->i8l_R : 0.0f, w2 = W / 255.0f;
+    if (l2) {
+        INNR_TRY(c->q_hat.ensure(std::max<size_t>(Q * Dq, 1) * sizeof(float)));
+        f32i8_l2_queries_kernel<<<(unsigned)((Q * Dq + 255) / 256), 256, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->i8l_R, w1, w2,
+                                                                                     c->q_hat.as<float>());
+        INNR_HIP_CHECK(hipGetLastError());
+        f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, nullptr, nullptr, qsum, ql1q);
+        INNR_HIP_CHECK(hipGetLastError());
+        l2_query_consts_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, Q, b->max_norm, cq, Cj);
+        INNR_HIP_CHECK(hipGetLastError());
+        Qp = c->q_hat.as<float>();
+    }
+    f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(l2 ? Qp : dQ, (uint32_t)Q, (uint32_t)Dq, cos ? invq : nullptr,
                                                                             cos ? c->q_hat.as<float>() : nullptr, qsum, ql1);
     INNR_HIP_CHECK(hipGetLastError());
-    INNR_TRY(prep_queries_i8(b, p, Qp, Q, qsum, alpha, offset));
+    INNR_TRY(prep_queries_i8(b, p, Qp, Q, qsum, alpha, offset, Dq));
     float* qc = c->misc.as<float>();
     // the reference's own accumulation against the true dot: (D + 2) u |q||v| (half of the f32 GEMM engine's cdu)
     const float cdu = 1.05f * (2.0f * (float)b->D + 8.0f) * 5.9604645e-08f;
-    f32i8_finish_bound_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, c->stream>>>(qc, (uint32_t)p.Qpad, (uint32_t)Q, ql1, c->q_norm.as<float>(),
-                                                                               alpha, cos ? cdu * 1.02f : cdu * b->max_norm, cos ? 1 : 0,
-                                                                               128.0f * alpha / 255.0f + offset, (float)b->D);
+    // (squared L2: the corpus' quantisation touches the 2 q_d only -- the |v|^2 limbs are exact integers, their encoding error and
+    //  the f32 terms are f32i8_l2_finish_kernel's)
+    f32i8_finish_bound_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, c->stream>>>(qc, (uint32_t)p.Qpad, (uint32_t)Q, l2 ? ql1q : ql1, c->q_norm.as<float>(),
+                                                                               alpha, l2 ? 0.0f : (cos ? cdu * 1.02f : cdu * b->max_norm), cos || l2 ? 1 : 0,
+                                                                               128.0f * alpha / 255.0f + offset, (float)Dq, l2 ? 2.0f : 1.0f, ql1);
     INNR_HIP_CHECK(hipGetLastError());
+    if (l2) {
+        // -|v|^2 = -W z1^ - w2 z2^ + K0 (+- nmax / 130050: the second limb's rounding; + the f32 roundings of z' = offset + alpha n /
+        // nmax, relative to |offset| + alpha, times W); the f32 squared-L2 engine's (6D + 40) u C_j covers the cached norms, the
+        // constants and the reference's own direct-difference sum
+        const float K0 = W * offset + w2 * (offset + 0.5f * alpha);
+        const float enc_err = b->i8l_nmax * (1.1f / 130050.0f + 3.0e-7f * (fabsf(offset) / alpha + 1.0f));
+        f32i8_l2_finish_kernel<<<(unsigned)((Q + 255) / 256), 256, 0, c->stream>>>(qc, (uint32_t)p.Qpad, (uint32_t)Q, cq, Cj, K0, enc_err,
+                                                                                1.05f * (6.0f * (float)b->D + 40.0f) * 5.9604645e-08f);
+        INNR_HIP_CHECK(hipGetLastError());
+    }
     const float* eq = qc + 3 * p.Qpad;
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
     INNR_HIP_CHECK(hipMemsetAsync(fallback, 0, Q * sizeof(uint32_t), c->stream));
@@ -2895,7 +2973,8 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
         // ---- completion pass: fixed thresholds x_k - E_j, global lists, exact re-score of everything collected ----
         INNR_TRY(c->seed_score.ensure(p.Qpad * sizeof(uint32_t)));
         uint32_t* thr = c->seed_score.as<uint32_t>();
-        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(collect_kth, (uint32_t)Q, 1u, eq, thr, (uint32_t)p.Qpad, 0u);
+        seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(collect_kth, (uint32_t)Q, 1u, eq, thr, (uint32_t)p.Qpad, 0u,
+                                                                                       l2 ? Cj : nullptr);
         INNR_HIP_CHECK(hipGetLastError());
         INNR_TRY(c->lists.ensure(p.Qpad * (size_t)kCollectCap * sizeof(uint32_t)));
         INNR_TRY(c->counts.ensure(p.Qpad * sizeof(uint32_t)));
@@ -2903,7 +2982,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
         I8Plan pl = p;
         pl.KP = kCollectCap;
         INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-        INNR_TRY(launch_gemm_i8<2>(b, pl, Q, qc, nullptr, 0, thr, cos ? b->Ai8n : b->Ai8));
+        INNR_TRY(launch_gemm_i8<2>(b, pl, Q, qc, nullptr, 0, thr, copy));
         INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
         INNR_TRY(collect_finish(b, metric, dQ, c->q_norm.as<float>(), Q, kout, d_out_idx, d_out_score, d_unresolved));
         return INNR_OK;  // (the caller reads ev[2..3] once it has synchronised)
@@ -2918,7 +2997,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
                                  c->seed_score.as<float>(), ScanExt(), kSeedN));
         uint32_t* sd = reinterpret_cast<uint32_t*>(c->seed_score.as<float>() + Q * kseed);
         seed_thresholds_eq_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->seed_score.as<float>(), (uint32_t)Q, kseed, eq, sd,
-                                                                                       (uint32_t)p.Qpad, kseed - 1);
+                                                                                       (uint32_t)p.Qpad, kseed - 1, l2 ? Cj : nullptr);
         INNR_HIP_CHECK(hipGetLastError());
         seed = sd;
     }
@@ -2929,18 +3008,20 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     const float* kmargin = nullptr;
     INNR_TRY(make_kmargin(c, 3, 0.0f, nullptr, nullptr, eq, 0.0f, nullptr, Q, p.Qpad, &kmargin));
     INNR_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
-    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, cos ? b->Ai8n : b->Ai8, kmargin, (uint32_t)kout));
+    INNR_TRY(launch_gemm_i8<0>(b, p, Q, qc, nullptr, 0, seed, copy, kmargin, (uint32_t)kout));
     INNR_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     INNR_TRY(run_select(c, c->lists.as<uint64_t>(), c->counts.as<uint32_t>(), p.nslices, (uint32_t)p.Qpad, p.cap, p.KP, (uint32_t)Q));
 #define INNR_RESCORE_EQ(METV, RKV)                                                                                   \
     rescore_kernel<METV, RKV><<<(unsigned)Q, 64, 0, c->stream>>>(b->V, b->ldN, (uint32_t)b->D, dQ, b->norms,           \
-                                                                 c->q_norm.as<float>(), nullptr, c->sel.as<uint64_t>(), \
+                                                                 c->q_norm.as<float>(), l2 ? Cj : nullptr, c->sel.as<uint64_t>(), \
                                                                  c->sel_cnt.as<uint32_t>(), p.KP, (uint32_t)kout, 0.0f, \
                                                                  b->index_base, d_out_idx, d_out_score, fallback, eq,   \
                                                                  !c->tune.rescore_all, gthr_bounds(c, p.Qpad, p.KP))
     const int rk = p.KP <= 64 ? 1 : (p.KP <= 128 ? 2 : 4);
     if (cos) {
         if (rk == 1) INNR_RESCORE_EQ(1, 1); else if (rk == 2) INNR_RESCORE_EQ(1, 2); else INNR_RESCORE_EQ(1, 4);
+    } else if (l2) {
+        if (rk == 1) INNR_RESCORE_EQ(2, 1); else if (rk == 2) INNR_RESCORE_EQ(2, 2); else INNR_RESCORE_EQ(2, 4);
     } else {
         if (rk == 1) INNR_RESCORE_EQ(0, 1); else if (rk == 2) INNR_RESCORE_EQ(0, 2); else INNR_RESCORE_EQ(0, 4);
     }
@@ -2958,7 +3039,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     *kept = p.KP;
     // (lists sized for a direct proof that mostly fail: the corpus' range is blown up by outliers; AUTO takes the bf16 filter,
     //  whose error is relative, on this corpus from now on -- and looks at the int8 one again every 64th call, innr_batch_knn_dev)
-    if (direct && Q >= 16) (cos ? b->i8n_weak : b->i8_weak) = redo.size() * 2 > Q;
+    if (direct && Q >= 16) (cos ? b->i8n_weak : (l2 ? b->i8l_weak : b->i8_weak)) = redo.size() * 2 > Q;
     // ONE more pass of this filter in collect mode settles the unproven queries (k beyond the direct lists: nearly all of them)
     if (redo.size() > 8 && !c->tune.no_completion) {
         std::vector<uint32_t> still;

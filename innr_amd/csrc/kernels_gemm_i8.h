@@ -96,9 +96,17 @@ __global__ __launch_bounds__(256) void pack_corpus_i8_kernel(const uint8_t* __re
 // describes (scalar.rs:366-368), except that here the second stage PROVES the answer: |v_d - (offset + alpha c_d / 255)| <=
 // alpha / 510 for every value inside the range, so the filter's score is within (alpha / 510) sum_d |q_d| of q.v.
 // rowscale (nullable): 1/||v|| per row -- the cosine copy quantises the normalised rows (range [-1, 1]).
+// sqn != null: the SQUARED-L2 copy (batch_knn, batch.rs:385-411, on this filter). C_j - |q - v|^2 = 2 q.v - |v|^2 + (C_j - |q|^2)
+// is a plain DOT PRODUCT of augmented vectors -- [2q, -w1 (R times), -w2] . [v, z1 (R times), z2] + constants -- so the kernel and
+// everything behind it stay the dot filter's: the row's |v|^2 = n is mapped into the corpus' own value range, z' = offset + alpha
+// n / nmax, and carried as TWO 8-bit limbs in D' - D = R + 1 more dimensions: z1 = the quantised z' in R dimensions (each with
+// query weight -w1 = -(nmax / alpha) / R, so that no single query entry dwarfs the 2 q_d and costs them their bits), z2 = the
+// residual z' - dequant(z1), stretched by 255, in one (weight -w2 = -(nmax / alpha) / 255). |n - n^| <= nmax / 130050.
 __global__ __launch_bounds__(256) void pack_corpus_f32_i8_kernel(const float* __restrict__ V, size_t ldN, uint32_t N, uint32_t D,
                                                                   uint32_t nk, size_t nthreads, float offset, float inv_alpha,
-                                                                  const float* __restrict__ rowscale, uint4* __restrict__ Ai8) {
+                                                                  const float* __restrict__ rowscale, uint4* __restrict__ Ai8,
+                                                                  const float* __restrict__ sqn = nullptr, uint32_t R = 0,
+                                                                  float inv_nmax = 0.0f) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= nthreads) return;
     const uint32_t i = (uint32_t)(t & 31), kg = (uint32_t)((t >> 5) & 3);
@@ -119,6 +127,22 @@ __global__ __launch_bounds__(256) void pack_corpus_f32_i8_kernel(const float* __
             const float4 x = *reinterpret_cast<const float4*>(V + (size_t)d * ldN + row0);
             v = (uint32_t)quantize_one(x.x * rs[0], offset, inv_alpha) | ((uint32_t)quantize_one(x.y * rs[1], offset, inv_alpha) << 8) |
                 ((uint32_t)quantize_one(x.z * rs[2], offset, inv_alpha) << 16) | ((uint32_t)quantize_one(x.w * rs[3], offset, inv_alpha) << 24);
+        } else if (sqn && d <= D + R) {  // the two limbs of |v|^2 (d < D + R: the first, d == D + R: the second)
+            const float4 n4 = *reinterpret_cast<const float4*>(sqn + row0);
+            const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+            const float alpha = 255.0f / inv_alpha;
+            v = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z1 = offset + alpha * (nn[r] * inv_nmax);
+                const uint32_t c1 = quantize_one(z1, offset, inv_alpha);
+                uint32_t code = c1;
+                if (d == D + R) {
+                    const float res = z1 - (offset + alpha * ((float)c1 * (1.0f / 255.0f)));  // within +- alpha / 510
+                    code = quantize_one(offset + 0.5f * alpha + res * 255.0f, offset, inv_alpha);
+                }
+                v |= code << (8 * r);
+            }
         }
         w[e] = v ^ 0x80808080u;
     }
@@ -129,7 +153,14 @@ __global__ __launch_bounds__(256) void pack_corpus_f32_i8_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             uint32_t byte = (w[e] >> (8 * rt)) & 0xffu;
-            if (row0 + rt >= N) byte = 0u;
+            if (row0 + rt >= N) {
+                // padding rows: c' = 0 (approximation = B_j: far below any bound of a dot / cosine call). Squared L2: c' = 0 in
+                // the |v|^2 limbs would read as a vector of norm^2 nmax / 2 AT the range's centre -- closer to every query
+                // than the corpus, survivors all (never appended: i >= N; at C2 the block holding them ran 23.6 M cycles against
+                // the others' 15.9 M, 12.9 ms against 8.9 for the kernel): the largest |v|^2 the limbs can say instead.
+                const uint32_t d = ks * 64 + kg * 16 + (uint32_t)e;
+                byte = (sqn && d >= D && d <= D + R) ? 0x7fu : 0u;
+            }
             o[e >> 2] |= byte << (8 * (e & 3));
         }
         out[rt * 32] = make_uint4(o[0], o[1], o[2], o[3]);
@@ -160,21 +191,44 @@ __global__ void f32i8_query_prep_kernel(const float* __restrict__ Qm, uint32_t Q
 // embeddings, tf-idf in [0, 1]: |centre| / alpha = 1/2)
 __global__ void f32i8_finish_bound_kernel(float* __restrict__ qc, uint32_t Qpad, uint32_t Q, const float* __restrict__ ql1,
                                           const float* __restrict__ qnorm, float alpha, float ref_scale, int cosine, float centre,
-                                          float D) {
+                                          float D, float l1_scale = 1.0f, const float* __restrict__ ql1_sum = nullptr) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Q) return;
     const float ref = cosine ? ref_scale : ref_scale * qnorm[j];
-    const float sum_err = fabsf(centre) * D * 6.0e-8f * ql1[j];
-    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + (alpha / 510.0f) * 1.002f * ql1[j] + sum_err + ref) * 1.0001f;
+    // (squared L2: ql1 = |q|_1 of the query, twice of which meets quantised corpus values; ql1_sum = that of the augmented query)
+    const float sum_err = fabsf(centre) * D * 6.0e-8f * (ql1_sum ? ql1_sum[j] : ql1[j]);
+    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + (alpha / 510.0f) * 1.002f * l1_scale * ql1[j] + sum_err + ref) * 1.0001f;
 }
 
+// the augmented query of the squared-L2 copy: [2 q_d, -w1 (R times), -w2]
+__global__ void f32i8_l2_queries_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, uint32_t R, float w1, float w2,
+                                        float* __restrict__ Qaug /*[Q][D + R + 1]*/) {
+    const uint32_t Da = D + R + 1;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Q * Da) return;
+    const uint32_t j = (uint32_t)(t / Da), d = (uint32_t)(t % Da);
+    Qaug[t] = d < D ? 2.0f * Qm[(size_t)j * D + d] : (d < D + R ? -w1 : -w2);
+}
+// ... and its constants: B_j += K0 + (C_j - |q_j|^2), E_j += the encoding of |v|^2 + the f32 squared-L2 engine's own terms
+__global__ void f32i8_l2_finish_kernel(float* __restrict__ qc, uint32_t Qpad, uint32_t Q, const float* __restrict__ cq /*C_j - |q_j|^2*/,
+                                       const float* __restrict__ Cj, float K0, float enc_err, float l2_scale) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Q) return;
+    const float B = qc[(size_t)Qpad + j] + K0 + cq[j];
+    qc[(size_t)Qpad + j] = B;
+    qc[3 * (size_t)Qpad + j] = (qc[3 * (size_t)Qpad + j] + enc_err + l2_scale * Cj[j] + 4.8e-7f * (fabsf(B) + fabsf(K0) + fabsf(cq[j]))) * 1.0001f;
+}
+
+// Cj != null: squared L2 -- kth_scores are distances, the bound lives in the score space C_j - distance
 __global__ void seed_thresholds_eq_kernel(const float* __restrict__ kth_scores /*[Q][KP], best first*/, uint32_t Q, uint32_t KP,
-                                          const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad, uint32_t pos) {
+                                          const float* __restrict__ eq, uint32_t* __restrict__ seed, uint32_t Qpad, uint32_t pos,
+                                          const float* __restrict__ Cj = nullptr) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Qpad) return;
     uint32_t o = 0;
     if (j < Q) {
-        const float t = kth_scores[(size_t)j * KP + pos] - eq[j] * 1.0001f - 1e-30f;  // pos: see seed_thresholds_kernel
+        const float x = kth_scores[(size_t)j * KP + pos];  // pos: see seed_thresholds_kernel
+        const float t = (Cj ? Cj[j] - x : x) - eq[j] * 1.0001f - 1e-30f;
         if (t - t == 0.0f) o = f32_ord(t) - 1u;
     }
     seed[j] = o;
@@ -565,7 +619,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8_filter_kernel(
 // folded into one word per lane: a probe build whose accumulators nobody reads loses its MFMAs to dead-code elimination -- the
 // first compile-time version of bits 1 and 32 "measured" a 4.1 ms K-loop that multiplied nothing); 4: count visiting wave
 // epilogues / survivors / bound re-derivations and the cycles they take into errflag[8..17]. Builds with bits 1, 8, 16 or 32 give
-// wrong answers and their calls fail after filling the stats.
+// wrong answers and their calls fail after filling the stats. 64 / 128 (with 1): no barrier in the K-loop / no LDS fragment reads.
 #ifndef INNR_I8H_PROBE
 #define INNR_I8H_PROBE 0
 #endif
@@ -584,6 +638,12 @@ constexpr int kI8hSurvCap = 128;  // survivors a wave queues before it must fini
 #define INNR_I8H_FLUSH_AT 48
 #endif
 constexpr int kI8hFlushEvery = INNR_I8H_FLUSH_EVERY, kI8hFlushAt = INNR_I8H_FLUSH_AT;
+// survivors a visit finishes per memory round trip (64 / kI8hPer lanes each): a visit's length is its number of round trips to HBM
+#ifndef INNR_I8H_PER
+#define INNR_I8H_PER 4
+#endif
+constexpr int kI8hPer = INNR_I8H_PER;
+static_assert(kI8hPer == 4 || kI8hPer == 8, "4 survivors x 16 lanes x 3 chunks, or 8 x 8 x 6, per pass of 48 chunks");
 static_assert(kI8hFlushAt + 64 <= kI8hSurvCap + 64 && kI8hFlushEvery >= 1, "list geometry");
 struct alignas(16) GemmI8hLds {
     alignas(16) char A[kI8Stages * kI8StageBytes];
@@ -720,8 +780,9 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     if (wu >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     uint32_t ns = 0;  // survivors queued in this wave's LDS list (wave-uniform; carried from tile to tile)
-    uint32_t pc_nvis = 0, pc_nsurv = 0, pc_npub = 0;
-    unsigned long long pc_visit = 0, pc_surv = 0, pc_tail = 0;  // cycles inside visits / inside the survivors' loops / publish + compaction
+    uint32_t pc_nvis = 0, pc_nsurv = 0, pc_npub = 0, pc_napp = 0, pc_nhit = 0;
+    unsigned long long pc_visit = 0, pc_surv = 0, pc_tail = 0, pc_queue = 0;
+    const unsigned long long pc_t0 = (kI8hProbe & 4) ? __builtin_readcyclecounter() : 0ull;  // cycles inside visits / inside the survivors' loops / publish + compaction
     for (uint32_t step0 = 0; step0 < total; step0 += kI8Lead) {
 #pragma unroll
         for (int r = 0; r < kI8Lead; ++r) {
@@ -732,8 +793,10 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
             for (int m = 0; m < 2; ++m) {
                 i32x4_t a[4];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt)
-                    a[rt] = *reinterpret_cast<const i32x4_t*>(stage + ((2 * m + half) * 128 + rt * 32 + C) * 16);
+                for (int rt = 0; rt < 4; ++rt) {
+                    if ((kI8hProbe & 128) && step0 > 0) a[rt] = i32x4_t{(int)step, (int)lane, rt, m};  // timing only: no LDS fragment reads
+                    else a[rt] = *reinterpret_cast<const i32x4_t*>(stage + ((2 * m + half) * 128 + rt * 32 + C) * 16);
+                }
                 constexpr int kYounger = 5 * kI8Lead - 2;
                 if (m == 0) use_after<kYounger>(breg[r][0], breg[r][1]);
                 else use_after<kYounger>(breg[r][2], breg[r][3]);
@@ -856,26 +919,29 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         auto flush = [&]() {
                             __builtin_amdgcn_wave_barrier();
                             const unsigned long long ps0 = probe ? __builtin_readcyclecounter() : 0ull;
-                            const int g_mine = lane >> 4, l16 = lane & 15;
-                            for (uint32_t e0 = 0; e0 < ns; e0 += 4) {
-                                const uint32_t nb = ns - e0 < 4u ? ns - e0 : 4u;
+                            constexpr int PER = kI8hPer, LPS = 64 / PER, CPL = 48 / LPS;  // lanes per survivor, chunks per lane and pass
+                            const int g_mine = lane / LPS, l16 = lane % LPS;
+                            for (uint32_t e0 = 0; e0 < ns; e0 += PER) {
+                                const uint32_t nb = ns - e0 < (uint32_t)PER ? ns - e0 : (uint32_t)PER;
                                 const uint32_t em = e0 + ((uint32_t)g_mine < nb ? (uint32_t)g_mine : 0u);
                                 const uint32_t hi_m = s.surv[wu][em][0], row_m = s.surv[wu][em][1], lc_m = s.surv[wu][em][2];
                                 const uint32_t rr = row_m & 127u;  // row inside its tile: 4 i_ + rt
                                 const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)(row_m >> 7) * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
                                 const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (q0 + 64 * wu + 32 * ((lc_m >> 8) & 1u) + (lc_m & 31u));
                                 int32_t part = 0;
+                                // (One pass of 64 chunks for 769 .. 1024 dimensions -- squared L2 at C2 is 842 -- beside this loop saved that
+                                //  shape its second round trip, 13.05 -> 12.49 ms, and cost the dot shape 8.19 -> 8.71: not kept.)
                                 for (uint32_t c0 = 0; c0 < nk * 4; c0 += 48) {  // 48 chunks (768 dimensions) per pass: three per lane
-                                    uint4 x[3], y[3];
+                                    uint4 x[CPL], y[CPL];
 #pragma unroll
-                                    for (int t = 0; t < 3; ++t) {
-                                        const uint32_t c = c0 + (uint32_t)l16 + 16u * (uint32_t)t;
+                                    for (int t = 0; t < CPL; ++t) {
+                                        const uint32_t c = c0 + (uint32_t)l16 + (uint32_t)LPS * (uint32_t)t;
                                         const bool on = (uint32_t)g_mine < nb && c < nk * 4;
                                         x[t] = on ? pa[(size_t)c * 128] : uint4{0u, 0u, 0u, 0u};
                                         y[t] = on ? pb[(size_t)c * 2 * Qpad] : uint4{0u, 0u, 0u, 0u};
                                     }
 #pragma unroll
-                                    for (int t = 0; t < 3; ++t) {
+                                    for (int t = 0; t < CPL; ++t) {
                                         part = __builtin_amdgcn_sdot4((int)x[t].x, (int)y[t].x, part, false);
                                         part = __builtin_amdgcn_sdot4((int)x[t].y, (int)y[t].y, part, false);
                                         part = __builtin_amdgcn_sdot4((int)x[t].z, (int)y[t].z, part, false);
@@ -883,12 +949,12 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                     }
                                 }
 #pragma unroll
-                                for (int off = 8; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+                                for (int off = LPS / 2; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
                                 for (uint32_t g = 0; g < nb; ++g) {
-                                    const int32_t lo = __builtin_amdgcn_readlane(part, 16 * (int)g);
-                                    const int32_t hiL = (int32_t)__builtin_amdgcn_readlane((int)hi_m, 16 * (int)g);
-                                    const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)row_m, 16 * (int)g);
-                                    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)lc_m, 16 * (int)g);
+                                    const int32_t lo = __builtin_amdgcn_readlane(part, LPS * (int)g);
+                                    const int32_t hiL = (int32_t)__builtin_amdgcn_readlane((int)hi_m, LPS * (int)g);
+                                    const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)row_m, LPS * (int)g);
+                                    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)lc_m, LPS * (int)g);
                                     const int L = (int)(lc & 63u);
                                     const bool c1 = ((lc >> 8) & 1u) != 0;  // query column tile (wave-uniform)
                                     const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)lo);
@@ -896,6 +962,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                         const uint32_t o = f32_ord(__builtin_fmaf(c1 ? Aj[1] : Aj[0], (float)V, c1 ? Bj[1] : Bj[0]));
                                         if (o >= (c1 ? thr[1] : thr[0]) && i < N) {
                                             const int ql = 64 * w + 32 * (c1 ? 1 : 0) + C;
+                                            if (probe) ++pc_napp;
                                             if (MODE == 2) {  // collect: the query's global list
                                                 const uint32_t pos = atomicAdd(counts + q0 + ql, 1u);
                                                 if (pos < KP) reinterpret_cast<uint32_t*>(lists)[(q0 + ql) * (size_t)KP + pos] = i;
@@ -988,7 +1055,9 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                         // of 16 sites: at most one entry per lane and round) -- which needs the visit's registers, so the visit
                         // starts before the walk.
                         bool rounds = false;
+                        const unsigned long long pq0 = probe ? __builtin_readcyclecounter() : 0ull;
                         if (any_hit) {
+                            pc_nhit += probe ? 1u : 0u;
                             uint32_t mine = 0;
 #pragma unroll
                             for (int ct = 0; ct < 2; ++ct)
@@ -1032,6 +1101,7 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
                                     }
                             }
                         }
+                        if (probe) pc_queue += __builtin_readcyclecounter() - pq0;
                         if (rounds || sync_flush || ns >= (uint32_t)kI8hFlushAt) {
                             const unsigned long long pt0 = probe ? __builtin_readcyclecounter() : 0ull;
                             pc_nvis += probe ? 1u : 0u;
@@ -1093,16 +1163,27 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
             }
             if (r == kI8Lead - 1) {  // one barrier per two K-steps: see gemm_bf16_filter_kernel
                 wait_but_youngest<5 * (kI8Stages - 4) + 4>();
-                __syncthreads();
+                if (!(kI8hProbe & 64)) __syncthreads();  // (probe bit 64, timing only: no barrier in the K-loop)
             }
         }
     }
     wait_all();
     __syncthreads();
+    if (kI8hProbe & 4)
+        for (int off = 32; off >= 1; off >>= 1) pc_napp += (uint32_t)__shfl_xor((int)pc_napp, off, 64);  // (counted by the lane that appends)
     if (MODE == 0 && (kI8hProbe & (4 | 1)) && lane == 0) {
         atomicAdd(errflag + 8, pc_nvis);
         atomicAdd(errflag + 9, pc_nsurv);
         atomicAdd(errflag + 10, pc_npub);
+        atomicAdd(errflag + 11, pc_napp);
+        atomicAdd(errflag + 18, pc_nhit);
+        atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 20), pc_queue);
+        if (kI8hProbe & 4) {  // the longest and the shortest wave of the launch (cycles / 16): what the slices' imbalance costs
+            const uint32_t dur = (uint32_t)((__builtin_readcyclecounter() - pc_t0) >> 4);
+            atomicMax(errflag + 22, dur);
+            atomicMax(errflag + 23, ~dur);
+            if (w == 0 && blockIdx.x < 512) errflag[128 + blockIdx.x] = dur;  // per block (the flags buffer holds 1024 words)
+        }
         atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 12), pc_visit);
         atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 14), pc_surv);
         atomicAdd(reinterpret_cast<unsigned long long*>(errflag + 16), pc_tail);

@@ -26,8 +26,8 @@ def test_bf16_filter_dot_matches_oracle(B, innr, n, dim, nq, k, filt):
                             ("l2", B.batch_knn_multi, oracle.batch_knn)):
         st = innr.KnnStats()
         idx, sc = fn(qs, vb, k, engine=engine, stats=st)
-        # squared L2 has no int8 filter: the bf16 one (|v|^2 and the query's constant in six more K columns) serves it
-        assert st.engine == (innr.KNN_MFMA_BF16 if metric == "l2" else engine)
+        # (squared L2 on the int8 filter: |v|^2 as two 8-bit limbs in R + 1 more dimensions of its own corpus copy)
+        assert st.engine == engine
         for j, q in enumerate(qs):
             oi, os_ = ofn(q, data, k)
             assert same_knn(metric, idx[j], sc[j], oi, os_), (metric, j, idx[j], oi, sc[j], os_)
@@ -55,8 +55,11 @@ def test_bf16_cosine_zero_norms_and_auto(B, innr):
         assert st.engine == innr.KNN_MFMA_BF16  # ... the bf16 one when the int8 one is ruled out (its copy exists already)
     _check_knn(B, innr, "dot", vb, data, qs, 10, innr.KNN_AUTO)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
-    assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter (there is no int8 one for it)
+    assert st.engine == innr.KNN_MFMA_I8  # squared L2 has its own int8 copy (D + R + 1 dimensions)
     _check_knn(B, innr, "l2", vb, data, qs, 10, innr.KNN_AUTO)
+    with _lib.default_context().option("no_auto_i8", 1):
+        B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_AUTO, stats=st)
+        assert st.engine == innr.KNN_MFMA_BF16
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_AUTO, stats=st)
     # k > 48: the int8 filter with lists of k + 16 and its completion pass (collect mode) behind them; same answers
     assert st.engine == innr.KNN_MFMA_I8
@@ -77,7 +80,7 @@ def test_bf16_engine_l2_and_what_the_f32_engine_still_serves(B, innr):
     st = innr.KnnStats()
     for engine in (innr.KNN_MFMA_BF16, innr.KNN_MFMA_I8):
         B.batch_knn_multi(qs, vb, 10, engine=engine, stats=st)
-        assert st.engine == innr.KNN_MFMA_BF16 and st.queries_fallback <= 2
+        assert st.engine == engine and st.queries_fallback <= 2
         _check_knn(B, innr, "l2", vb, data, qs, 10, engine)
     # D + 6 columns no longer fit the last K-step pair (D = 64 -> 128 columns), a query far outside the corpus, a zero query,
     # a zero row, a corpus far from the origin (|v|^2 dwarfs the differences: proofs fail, answers must not)
@@ -121,8 +124,8 @@ def test_bf16_filter_on_a_prefix_view(B, innr):
 
 def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     """INNR_KNN_MFMA_I8 on an f32 batch: a corpus with outliers (the global range is wide, the bound large: proofs fail,
-    answers must not), a constant corpus (nothing to quantise against: the f32 engine serves it), non-finite values, squared L2
-    (served by the bf16 filter), k > 48 (lists of k + 16 + the completion pass), near-tie data, zero-norm rows / queries under cosine."""
+    answers must not), a constant corpus (nothing to quantise against: the f32 engine serves it), non-finite values, squared L2,
+    k > 48 (lists of k + 16 + the completion pass), near-tie data, zero-norm rows / queries under cosine."""
     rows, data = _corpus(70_000, 64, 13, uniform=True)
     qs = _queries(40, 64, 3, uniform=True)
     out = rows.copy()
@@ -141,7 +144,9 @@ def test_int8_filter_of_f32_corpus_special_cases(B, innr):
     _check_knn(B, innr, "dot", bad, oracle.from_rows(bad), qs, 5, innr.KNN_MFMA_I8)
     vb = B.VerticalBatch.from_rows(rows)
     B.batch_knn_multi(qs, vb, 10, engine=innr.KNN_MFMA_I8, stats=st)
-    assert st.engine == innr.KNN_MFMA_BF16  # squared L2: the bf16 filter
+    assert st.engine == innr.KNN_MFMA_I8  # squared L2: the augmented copy
+    _check_knn(B, innr, "l2", out, oracle.from_rows(out), qs, 10, innr.KNN_MFMA_I8)  # outliers: |v|^2 up to 1e8 beside ~21
+    _check_knn(B, innr, "l2", bad, oracle.from_rows(bad), qs, 5, innr.KNN_MFMA_I8)
     B.batch_knn_dot_multi(qs, vb, 100, engine=innr.KNN_MFMA_I8, stats=st)
     assert st.engine == innr.KNN_MFMA_I8  # k > 48: lists of k + 16 and the filter's completion pass
     _check_knn(B, innr, "dot", vb, data, qs, 100, innr.KNN_MFMA_I8)
@@ -178,3 +183,27 @@ def test_int8_filter_off_centre_range_and_extreme_thresholds(B, innr):
             assert st.engine == innr.KNN_MFMA_I8
             i0, s0 = fn(qs[:24], batch, k, engine=innr.KNN_EXACT)
             assert np.array_equal(i1[:24], i0) and bits_equal(s1[:24], s0)
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 64, 130, 10), (70_000, 100, 40, 100), (66_000, 7, 33, 5), (100_000, 200, 3, 10),
+                                        (70_000, 64, 1, 48)])
+def test_int8_filter_squared_l2(B, innr, n, dim, nq, k):
+    """squared L2 on the int8 filter (pack_corpus_f32_i8_kernel: the corpus copy carries |v|^2 as two 8-bit limbs in R + 1 more
+    dimensions, the query is [2q, -w1 x R, -w2]): centred rows with unequal norms, an off-centre range (ReLU-like: the offset
+    terms of K0 and B_j matter), rows far from the origin (C_j - distance loses bits: the f32 terms of the bound), queries far
+    outside the corpus; k beyond the direct lists goes through the collect pass. Same distances bit for bit, same index lists."""
+    rows, _ = _corpus(n, dim, 31, uniform=True)
+    rows = (rows * (1.0 + 0.7 * np.sin(np.arange(n, dtype=np.float32)))[:, None]).astype(np.float32)
+    qs = _queries(nq, dim, 777, uniform=True)
+    st = innr.KnnStats()
+    vb = _check_knn(B, innr, "l2", rows, oracle.from_rows(rows), qs, k, innr.KNN_MFMA_I8)
+    B.batch_knn_multi(qs, vb, k, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8
+    if nq >= 16 and k <= 48:
+        assert st.queries_fallback <= max(2, nq // 10), st.queries_fallback
+    relu = np.maximum(rows, 0).astype(np.float32)
+    _check_knn(B, innr, "l2", relu, oracle.from_rows(relu), np.abs(qs), k, innr.KNN_MFMA_I8)
+    far = (rows + np.float32(50.0)).astype(np.float32)
+    _check_knn(B, innr, "l2", far, oracle.from_rows(far), (qs + np.float32(50.0)).astype(np.float32), k, innr.KNN_MFMA_I8)
+    _check_knn(B, innr, "l2", vb, oracle.from_rows(rows), (qs * np.float32(40.0)).astype(np.float32), k, innr.KNN_MFMA_I8)
+    _check_knn(B, innr, "dot", vb, oracle.from_rows(rows), qs, min(k, 48), innr.KNN_MFMA_I8)  # (the dot copy beside it, same range)

@@ -186,11 +186,14 @@ def test_knn_auto_engine_selection(B, innr):
     assert np.array_equal(i1, e1) and bits_equal(s1, es1)
     B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
     assert st.engine == innr.KNN_MFMA_I8
-    B.batch_knn_multi(_queries(8, 64, uniform=True), vb, 5, stats=st)
-    assert st.engine == innr.KNN_EXACT  # squared L2, 8 queries: one exact pass
+    B.batch_knn_multi(_queries(3, 64, uniform=True), vb, 5, stats=st)
+    assert st.engine == innr.KNN_EXACT  # squared L2, 3 queries, no copy for it yet: one exact pass
     B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
-    assert st.engine == innr.KNN_MFMA_BF16 and st.queries_fallback <= 1
+    assert st.engine == innr.KNN_MFMA_I8 and st.queries_fallback <= 1  # (squared L2 has its own int8 copy)
     from innr_amd import _lib
+    with _lib.default_context().option("no_auto_i8", 1):
+        B.batch_knn_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
+        assert st.engine == innr.KNN_MFMA_BF16 and st.queries_fallback <= 1
     with _lib.default_context().option("no_auto_bf16", 1):  # no low-precision filter at all: the f32 GEMM engine
         B.batch_knn_dot_multi(_queries(64, 64, uniform=True), vb, 5, stats=st)
         assert st.engine == innr.KNN_MFMA

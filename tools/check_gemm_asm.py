@@ -22,7 +22,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "innr_amd", "lib", "asm", "api.s")
 s = open(path).read()
 KERNELS = r"(?:18gemm_filter_kernel|23gemm_bf16_filter_kernel|21gemm_i8_filter_kernel|22gemm_i8h_filter_kernel)"
 names = [n for n in re.findall(r"^(_ZN4innr" + KERNELS + r"\S+):", s, flags=re.M) if not n.endswith(".kd")]

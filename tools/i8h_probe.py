@@ -5,6 +5,7 @@ corpus stages from L2, 32: no epilogue at all, 4: count visiting wave epilogues 
 Build the variants on the build box, then run on the GPU box:
     for b in 1 4 33; do make -C innr_amd/csrc LIBDIR=../lib_probe$b EXTRA=-DINNR_I8H_PROBE=$b all; done
     python tools/i8h_probe.py [lib dirs ...]          (default: innr_amd/lib and every innr_amd/lib_probe*)
+INNR_PROBE_METRIC=dot|cos|l2 picks the call (squared L2: the augmented copy, 14 K-steps at C2 instead of 12).
 """
 import glob
 import os
@@ -24,7 +25,8 @@ best = None
 for it in range(4):
     st = KnnStats()
     try:
-        B.batch_knn_dot_multi(q, vb, 10, engine=KNN_MFMA_I8, stats=st)
+        fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[os.environ.get("INNR_PROBE_METRIC", "dot")]
+        fn(q, vb, 10, engine=KNN_MFMA_I8, stats=st)
     except Exception:  # a timing build: the library fills the stats and refuses to return results
         pass
     if it and (best is None or st.gemm_ms < best.gemm_ms):
@@ -33,5 +35,5 @@ print(f"{os.environ.get('INNR_HIP_LIB_PATH', 'default')}: kernel {best.gemm_ms:.
 '''
 libs = sys.argv[1:] or ([os.path.join(ROOT, "innr_amd", "lib")] + sorted(glob.glob(os.path.join(ROOT, "innr_amd", "lib_probe*"))))
 for d in libs:
-    env = dict(os.environ, INNR_HIP_LIB_PATH=os.path.join(os.path.abspath(d), "libinnr_hip.so"))
+    env = dict(os.environ, INNR_HIP_LIB_PATH=os.path.join(os.path.abspath(d), "libinnr_hip.so"), INNR_NO_COMPLETION="1")  # (kernel ms = the first pass alone)
     subprocess.run([sys.executable, "-c", code], env=env, check=False)

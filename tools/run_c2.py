@@ -1,5 +1,5 @@
 """One process = the C2 call on one engine, a few times (the unit rocprofv3 wraps: tools/profile_c2_filters.sh).
-    python3 tools/run_c2.py i8|bf16|f32 [k] [metric dot|cos|l2] [queries]"""
+    python3 tools/run_c2.py i8|bf16|f32 [k] [metric dot|cos|l2] [queries] [dimension]"""
 import os
 import sys
 
@@ -12,9 +12,10 @@ eng = {"i8": KNN_MFMA_I8, "bf16": KNN_MFMA_BF16, "f32": KNN_MFMA}[sys.argv[1] if
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 metric = sys.argv[3] if len(sys.argv) > 3 else "dot"
 nq = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+dim = int(sys.argv[5]) if len(sys.argv) > 5 else 768
 fn = {"dot": B.batch_knn_dot_multi, "cos": B.batch_knn_cosine_multi, "l2": B.batch_knn_multi}[metric]
-vb = B.VerticalBatch.generate(10_000_000, 768, 0)
-q = np.random.default_rng(0xBE7C).uniform(-1, 1, size=(nq, 768)).astype(np.float32)
+vb = B.VerticalBatch.generate(10_000_000, dim, 0)
+q = np.random.default_rng(0xBE7C).uniform(-1, 1, size=(nq, dim)).astype(np.float32)
 best = None
 for it in range(5):
     st = KnnStats()

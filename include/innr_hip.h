@@ -69,7 +69,8 @@ typedef int innr_status;
                             * limb bounded in the filter and computed exactly for the survivors (lists of 256: a 16-bit value, both
                             * limbs on the pipe). Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call.
                             * INNR_KNN_AUTO picks it for query batches on large code corpora.
-                            * innr_batch_knn[_dev] on an F32 batch (dot, cosine; k <= 48; squared L2 goes to INNR_KNN_MFMA_BF16): the corpus scalar-quantised once with a
+                            * innr_batch_knn[_dev] on an F32 batch (dot, cosine, squared L2 -- whose copy carries |v|^2 as two 8-bit
+                            * limbs in up to 121 more dimensions; k <= INNR_MAX_K): the corpus scalar-quantised once with a
                             * single (offset, alpha) -- quantize_u8 with the corpus' own range, the first stage of the two-stage
                             * pipeline of scalar.rs:366-368 -- filtered on the integer pipe, re-scored on the f32 corpus and
                             * PROVEN against (alpha / 510) |q|_1 + the query's quantisation; unproven queries redone on the f32

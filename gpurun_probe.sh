@@ -1,4 +1,10 @@
 set -e
 mkdir -p gpurun_out
-for a in "i8 10 l2" "i8 100 l2" "i8 10 l2 1024 640" "i8 10 l2 64" "i8 10 l2 8" "bf16 10 l2 64"; do timeout -k 10 300 python3 tools/run_c2.py $a; done > gpurun_out/l2_c2.log 2>&1
-grep C2 gpurun_out/l2_c2.log
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
+tail -3 gpurun_out/gpu_tests.log
+timeout -k 10 400 python3 tools/bench_maxsim.py > gpurun_out/ms_c4.json 2> gpurun_out/ms_c4.err
+python3 -c "
+import json; d=json.load(open('gpurun_out/ms_c4.json'))
+for k,v in d.items():
+    if isinstance(v,dict): print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ('scan_ms','total_ms','scan_GBps')})
+"

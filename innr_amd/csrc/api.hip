@@ -3287,12 +3287,15 @@ static innr_status maxsim_scan_exact(innr_docs* d, int cosine, size_t Tq, const 
     const uint32_t docs_per_wave = 64 / Tp;
     const size_t nwaves_needed = (nslots + docs_per_wave - 1) / docs_per_wave;
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((nwaves_needed + 3) / 4, (size_t)c->num_cus * 2));
-    INNR_TRY(c->q_kmajor.ensure((size_t)kMsQ * std::max<size_t>(dim, 8) * sizeof(float) * 4));  // packed query (either engine)
+    const size_t qpk_floats = (size_t)kMsQ * std::max<size_t>(dim, 8) * 4;
+    INNR_TRY(c->q_kmajor.ensure((qpk_floats + kMsQ) * sizeof(float)));  // packed query (either engine) + sqrt of the pass' squared norms
     float* qpk = c->q_kmajor.as<float>();
+    float* saa = qpk + qpk_floats;
     for (size_t p0 = 0; p0 < Tq; p0 += kMsQ) {
         const uint32_t nq = (uint32_t)std::min<size_t>(kMsQ, Tq - p0);
         const float* qp = c->q_row.as<float>() + p0 * dim;
         const float* aa = c->q_norm.as<float>() + p0;
+        if (cosine) sqrt_kernel<<<1, kMsQ, 0, c->stream>>>(aa, nq, saa);
 #define INNR_MS_LAUNCH(COSV, NQV)                                                                                       \
     do {                                                                                                                \
         const unsigned npk = (unsigned)(dim / 4) * NQV * 4;                                                             \
@@ -3301,11 +3304,11 @@ static innr_status maxsim_scan_exact(innr_docs* d, int cosine, size_t Tq, const 
         if (d->T > 64)                                                                                                  \
             maxsim_scan_kernel<COSV, NQV, true><<<blocks, kMsThreads, 0, c->stream>>>(                                  \
                 d->tok, d->doc_len, (uint32_t)nslots, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                   \
-                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids);                                                       \
+                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids, COSV ? saa : nullptr);                                 \
         else                                                                                                            \
             maxsim_scan_kernel<COSV, NQV, false><<<blocks, kMsThreads, 0, c->stream>>>(                                 \
                 d->tok, d->doc_len, (uint32_t)nslots, (uint32_t)d->T, Tp, (uint32_t)dim, qp, qpk, nq,                   \
-                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids);                                                       \
+                COSV ? aa : nullptr, out, out, p0 == 0, doc_ids, COSV ? saa : nullptr);                                 \
     } while (0)
         if (cosine) {
             if (nq <= 8) INNR_MS_LAUNCH(true, 8); else if (nq <= 16) INNR_MS_LAUNCH(true, 16); else INNR_MS_LAUNCH(true, 32);

@@ -93,23 +93,27 @@ __device__ __forceinline__ void maxsim_bb(float (&bb)[4], const float4& d) {
 // One full burst: 8 chunks x NQ/4 groups, software-pipelined over the flat group sequence g = 0..G-1 (a pack
 // expansion, so that every load offset is an immediate). qb = packed query at chunk c0: group (b, gi) sits at
 // qb + (b*NQ + 4*gi)*4 floats.
+// The groups go in PAIRS (round 3): scalar loads return out of order, so a wave can only ever wait for ALL of its loads
+// (lgkmcnt(0)) -- with one s_load_dwordx16 requested per group, one group ahead, a load had the 16 packed VALU instructions of
+// one group (~85 cycles, twice that with the SIMD's other wave) to come back in, and the scan ran at 32 T results/s against
+// the 60 T/s the bare mul + add chains reach (tools/valu_rate.hip). Two loads per wait, for the pair after the current one,
+// double the cover at the price of 32 more SGPRs (4 x 16 hold query operands).
+template <int NQ>
+__device__ __forceinline__ constexpr int maxsim_group_off(int g) {  // byte offset of group g's operands from qb
+    return ((g / (NQ / 4)) * NQ + 4 * (g % (NQ / 4))) * 16;
+}
+__device__ __forceinline__ void swait0_pair(f32x16& a, f32x16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
+#ifdef INNR_MS_PROBE_NOMATH  // tools/maxsim_probe.hip: loads only (one group's arithmetic per chunk keeps them live)
 template <int NQ, bool COS, int g>
 __device__ __forceinline__ void maxsim_step(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
                                             const float* qb, f32x16 (&buf)[2]) {
     constexpr int GPC = NQ / 4, G = kMsBurst * GPC, b = g / GPC, gi = g % GPC;
-#ifdef INNR_MS_PROBE_NOMATH  // tools/maxsim_probe.hip: loads only (one group's arithmetic per chunk keeps them live)
     if (gi > 0) return;
     swait0(buf[b & 1]);
     if (g + GPC < G) sload16<((g + GPC) / GPC) * NQ * 16>(buf[(b + 1) & 1], qb);
     maxsim_group<NQ>(acc, buf[b & 1], 0, dv[b]);
-#else
-    swait0(buf[g & 1]);
-    if (g + 1 < G) sload16<(((g + 1) / GPC) * NQ + 4 * ((g + 1) % GPC)) * 16>(buf[(g + 1) & 1], qb);
-    if (COS && gi == 0) maxsim_bb(bb, dv[b]);
-    maxsim_group<NQ>(acc, buf[g & 1], 4 * gi, dv[b]);
-#endif
 }
-
 template <int NQ, bool COS, int... g>
 __device__ __forceinline__ void maxsim_burst_seq(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
                                                  const float* qb, std::integer_sequence<int, g...>) {
@@ -117,12 +121,45 @@ __device__ __forceinline__ void maxsim_burst_seq(f32x2 (&acc)[NQ][2], float (&bb
     sload16<0>(buf[0], qb);
     (maxsim_step<NQ, COS, g>(acc, bb, dv, qb, buf), ...);
 }
-
 template <int NQ, bool COS>
 __device__ __forceinline__ void maxsim_burst(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
                                              const float* qb) {
     maxsim_burst_seq<NQ, COS>(acc, bb, dv, qb, std::make_integer_sequence<int, kMsBurst * (NQ / 4)>{});
 }
+#else
+template <int NQ, bool COS, int p>
+__device__ __forceinline__ void maxsim_step2(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                             const float* qb, f32x16 (&buf)[2][2]) {
+    constexpr int GPC = NQ / 4, G = kMsBurst * GPC, g0 = 2 * p, g1 = 2 * p + 1;
+    static_assert(G % 2 == 0, "groups are visited in pairs");
+    swait0_pair(buf[p & 1][0], buf[p & 1][1]);
+#ifdef INNR_MS_PROBE_NOSLOAD  // tools/maxsim_probe.hip: the arithmetic on stale operands -- what the scalar loads cost
+    if (p == 0) {
+#else
+    if (g0 + 2 < G) {
+#endif
+        sload16<maxsim_group_off<NQ>(g0 + 2)>(buf[(p + 1) & 1][0], qb);
+        sload16<maxsim_group_off<NQ>(g1 + 2)>(buf[(p + 1) & 1][1], qb);
+    }
+    if (COS && g0 % GPC == 0) maxsim_bb(bb, dv[g0 / GPC]);
+    maxsim_group<NQ>(acc, buf[p & 1][0], 4 * (g0 % GPC), dv[g0 / GPC]);
+    if (COS && g1 % GPC == 0) maxsim_bb(bb, dv[g1 / GPC]);
+    maxsim_group<NQ>(acc, buf[p & 1][1], 4 * (g1 % GPC), dv[g1 / GPC]);
+}
+template <int NQ, bool COS, int... p>
+__device__ __forceinline__ void maxsim_burst_seq(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                                 const float* qb, std::integer_sequence<int, p...>) {
+    f32x16 buf[2][2];
+    sload16<maxsim_group_off<NQ>(0)>(buf[0][0], qb);
+    sload16<maxsim_group_off<NQ>(1)>(buf[0][1], qb);
+    (maxsim_step2<NQ, COS, p>(acc, bb, dv, qb, buf), ...);
+}
+template <int NQ, bool COS>
+__device__ __forceinline__ void maxsim_burst(f32x2 (&acc)[NQ][2], float (&bb)[4], const float4 (&dv)[kMsBurst],
+                                             const float* qb) {
+    maxsim_burst_seq<NQ, COS>(acc, bb, dv, qb, std::make_integer_sequence<int, kMsBurst * (NQ / 4) / 2>{});
+}
+#endif
 
 __device__ __forceinline__ void maxsim_load_burst(float4 (&dv)[kMsBurst], const float* __restrict__ row, uint32_t c0, int lane) {
 #pragma unroll
@@ -133,6 +170,57 @@ __device__ __forceinline__ void maxsim_load_burst(float4 (&dv)[kMsBurst], const 
         dv[b] = *reinterpret_cast<const float4*>(row + 4 * (c0 + b));
 #endif
     }
+}
+
+// The max over a document's TP token lanes for NQ query tokens at once, as a TRANSPOSING butterfly: a plain butterfly per query
+// token costs log2(TP) exchanges each (32 x 6 at C4); here the step with lane offset OFF also halves what a lane holds -- lanes
+// with bit OFF clear keep the lower half of the values, the others the upper half, each sends the half it gives up -- until
+// one value per lane is left (then, or at offset 1, plain steps): NQ/2 + NQ/4 + ... exchanges instead of NQ log2(TP). Query
+// token qi's maximum ends up in slot ms_tmax_slot(qi) of the segment's lanes whose bits match ms_tmax_lane(qi).
+// (max is order-free here: v_max_f32 ignores a NaN operand unless both are, and orders -0 < +0.)
+template <int NQ, int N, int OFF>
+__device__ __forceinline__ void ms_tmax(float (&v)[NQ], int lane) {
+    if constexpr (OFF >= 1) {
+        if constexpr (N > 1 && OFF >= 2) {
+            constexpr int H = N / 2;
+            const bool up = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const float send = up ? v[i] : v[i + H];
+                const float keep = up ? v[i + H] : v[i];
+                v[i] = fmaxf(keep, __shfl_xor(send, OFF, 64));
+            }
+            ms_tmax<NQ, H, OFF / 2>(v, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], __shfl_xor(v[i], OFF, 64));
+            ms_tmax<NQ, N, OFF / 2>(v, lane);
+        }
+    }
+}
+constexpr int ms_tmax_left(int NQ, int TP) {  // values per lane after the transposing steps
+    int n = NQ;
+    for (int off = TP / 2; off >= 2; off /= 2)
+        if (n > 1) n /= 2;
+    return n;
+}
+constexpr int ms_tmax_lane(int NQ, int TP, int qi) {  // lane bits (inside the segment) of the lanes that hold query token qi
+    int n = NQ, idx = qi, bits = 0;
+    for (int off = TP / 2; off >= 2; off /= 2)
+        if (n > 1) {
+            n /= 2;
+            if (idx >= n) { bits |= off; idx -= n; }
+        }
+    return bits;
+}
+constexpr int ms_tmax_slot(int NQ, int TP, int qi) {
+    int n = NQ, idx = qi;
+    for (int off = TP / 2; off >= 2; off /= 2)
+        if (n > 1) {
+            n /= 2;
+            if (idx >= n) idx -= n;
+        }
+    return idx;
 }
 
 // qpk[(c*NQ + qi)*4 + e] = qtok[qi*dim + 4c + e] (qi >= nq_valid rows are zero in qtok already)
@@ -152,12 +240,15 @@ __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
     uint32_t dim, const float* __restrict__ qtok /*[NQ][dim], zero-padded*/,
     const float* __restrict__ qpk /*[dim/4][NQ][4] packed copy*/, uint32_t nq,
     const float* __restrict__ q_aa /*[nq] COS*/, const float* __restrict__ partial_in, float* __restrict__ out,
-    bool first_pass, const uint32_t* __restrict__ doc_ids /*null: slot s is document s; else document doc_ids[s]*/) {
+    bool first_pass, const uint32_t* __restrict__ doc_ids /*null: slot s is document s; else document doc_ids[s]*/,
+    const float* __restrict__ q_saa = nullptr /*[nq] COS: sqrt(q_aa), the same rounding, once per query instead of per lane*/) {
     const int lane = threadIdx.x & 63;
     const uint32_t docs_per_wave = 64 / Tp;
     const uint32_t wave = (blockIdx.x * kMsThreads + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * kMsThreads) >> 6;
     const uint32_t chunks = dim / 4;
+    // the epilogue's form (wave-uniform, fixed for the launch): 1 = the transposing butterfly over a compile-time segment width
+    const int tmode = (dim % 4 == 0 && (Tp == 64 || Tp == 32 || Tp == 16 || Tp == 8)) ? 1 : 0;
     for (uint32_t dbase = wave * docs_per_wave; dbase < ndocs; dbase += nwaves * docs_per_wave) {
         const uint32_t slot = dbase + lane / Tp;  // output position; ndocs = number of slots
         const uint32_t doc = (slot < ndocs && doc_ids) ? doc_ids[slot] : slot;
@@ -212,31 +303,83 @@ __global__ __launch_bounds__(kMsThreads, 2) void maxsim_scan_kernel(
                 tailv[e] = row[chunks * 4 + e];
                 if (COS) sbb = ex::mad2(sbb, tailv[e], tailv[e]);
             }
+#ifdef INNR_MS_PROBE_NOEPI  // tools/maxsim_probe.hip: the hot loop alone (the accumulators folded into one value per lane)
+            {
+                float f = 0.0f;
 #pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) {
-                if ((uint32_t)qi < nq) {
-                    float sdot = ex::add(ex::add(ex::add(acc[qi][0].x, acc[qi][0].y), acc[qi][1].x), acc[qi][1].y);
-                    for (uint32_t e = 0; e < ntail; ++e) sdot = ex::mad2(sdot, qtok[(size_t)qi * dim + chunks * 4 + e], tailv[e]);
-                    float sc = sdot;
-                    if (COS) {  // dense.rs:341-345
-                        const float aa = q_aa[qi];
-                        constexpr float kEpsSq = INNR_NORM_EPSILON * INNR_NORM_EPSILON;  // lib.rs:184
-                        sc = (aa > kEpsSq && sbb > kEpsSq) ? ex::div(sdot, ex::mul(ex::sqrt(aa), ex::sqrt(sbb))) : 0.0f;
-                    }
-                    sc = live ? sc : -INFINITY;  // tokens beyond the document's length do not take part in the max
-                    best[qi] = fmaxf(best[qi], wave_max_seg(sc, (int)Tp));
-                }
+                for (int qi = 0; qi < NQ; ++qi) f += (acc[qi][0].x + acc[qi][0].y) + (acc[qi][1].x + acc[qi][1].y);
+                best[0] = fmaxf(best[0], f + sbb + (float)ntail);
             }
+#else
+            // Per query token: the lane's dot product, then the max over the document's Tp token lanes. With the segment width a
+            // run-time value the 32 butterflies were 32 loops (and the tail's per-token pointers 146 spilled SGPRs): this epilogue
+            // cost 31 % of the kernel at C4 (tools/maxsim_probe.hip, -DINNR_MS_PROBE_NOEPI: 3.20 -> 2.19 ms on 200 K documents).
+            // Now one wave-uniform switch picks straight-line code for the segment width -- the transposing butterfly ms_tmax --;
+            // a dimension that is not a multiple of four, or fewer than 8 tokens per document, keep the general form.
+            const float sqrt_bb = COS ? ex::sqrt(sbb) : 0.0f;
+            auto epilogue = [&](auto tp_tag, auto tail_tag) {
+                constexpr int TPC = decltype(tp_tag)::value;  // 0: run-time width
+                constexpr bool TAIL = decltype(tail_tag)::value;
+                float val[NQ];
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    if ((uint32_t)qi < nq) {
+                        float sdot = ex::add(ex::add(ex::add(acc[qi][0].x, acc[qi][0].y), acc[qi][1].x), acc[qi][1].y);
+                        if (TAIL)
+                            for (uint32_t e = 0; e < ntail; ++e) sdot = ex::mad2(sdot, qtok[(size_t)qi * dim + chunks * 4 + e], tailv[e]);
+                        float sc = sdot;
+                        if (COS) {  // dense.rs:341-345
+                            const float aa = q_aa[qi];
+                            constexpr float kEpsSq = INNR_NORM_EPSILON * INNR_NORM_EPSILON;  // lib.rs:184
+                            sc = (aa > kEpsSq && sbb > kEpsSq) ? ex::div(sdot, ex::mul(q_saa ? q_saa[qi] : ex::sqrt(aa), sqrt_bb)) : 0.0f;
+                        }
+                        sc = live ? sc : -INFINITY;  // tokens beyond the document's length do not take part in the max
+                        if (TPC == 0) best[qi] = fmaxf(best[qi], wave_max_seg(sc, (int)Tp));
+                        else val[qi] = sc;
+                    } else if (TPC != 0) {
+                        val[qi] = -INFINITY;  // (a padded query token: computed, never summed)
+                    }
+                }
+                if constexpr (TPC != 0) {  // transposed: best[s] = running max of slot s (ms_tmax)
+                    ms_tmax<NQ, NQ, TPC / 2>(val, lane);
+#pragma unroll
+                    for (int s2 = 0; s2 < ms_tmax_left(NQ, TPC); ++s2) best[s2] = fmaxf(best[s2], val[s2]);
+                }
+            };
+            using std::integral_constant;
+            if (tmode == 0 && ntail != 0) epilogue(integral_constant<int, 0>(), integral_constant<bool, true>());
+            else if (tmode == 0) epilogue(integral_constant<int, 0>(), integral_constant<bool, false>());
+            else if (Tp == 64) epilogue(integral_constant<int, 64>(), integral_constant<bool, false>());
+            else if (Tp == 32) epilogue(integral_constant<int, 32>(), integral_constant<bool, false>());
+            else if (Tp == 16) epilogue(integral_constant<int, 16>(), integral_constant<bool, false>());
+            else epilogue(integral_constant<int, 8>(), integral_constant<bool, false>());
+#endif
         }
         // sum over query tokens in token order, folded from -0.0 (first pass) or from the previous passes' total
-        if (t == 0 && slot < ndocs) {
-            float total = first_pass ? -0.0f : partial_in[slot];
+        float total = (t == 0 && slot < ndocs && !first_pass) ? partial_in[slot] : -0.0f;
+        auto fold = [&](auto tp_tag) {
+            constexpr int TPC = decltype(tp_tag)::value;
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi)
-                if ((uint32_t)qi < nq) total = ex::add(total, best[qi]);
-            out[slot] = (len == 0) ? 0.0f : total;  // empty document -> 0.0 (maxsim.rs:97-99)
-        }
+                if ((uint32_t)qi < nq) {
+                    float b;
+                    if constexpr (TPC == 0) b = best[qi];
+                    else b = __shfl(best[ms_tmax_slot(NQ, TPC, qi)], (lane & ~(TPC - 1)) | ms_tmax_lane(NQ, TPC, qi), 64);  // (every lane takes part)
+                    total = ex::add(total, b);
+                }
+        };
+        if (tmode == 0) fold(std::integral_constant<int, 0>());
+        else if (Tp == 64) fold(std::integral_constant<int, 64>());
+        else if (Tp == 32) fold(std::integral_constant<int, 32>());
+        else if (Tp == 16) fold(std::integral_constant<int, 16>());
+        else fold(std::integral_constant<int, 8>());
+        if (t == 0 && slot < ndocs) out[slot] = (len == 0) ? 0.0f : total;  // empty document -> 0.0 (maxsim.rs:97-99)
     }
+}
+
+__global__ void sqrt_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ y) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = ex::sqrt(x[i]);
 }
 
 // aa[i] = sum of squares of query token i in cosine_portable's 4-way order (dense.rs:288-339)

@@ -1,5 +1,5 @@
 // maxsim_probe.hip -- where does maxsim_scan_kernel's time go? Build three ways and compare:
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off [-DINNR_MS_PROBE_NOLOAD | -DINNR_MS_PROBE_NOMATH] \
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off [-DINNR_MS_PROBE_NOLOAD | -DINNR_MS_PROBE_NOMATH | -DINNR_MS_PROBE_NOSLOAD] \
 //         -o maxsim_probe tools/maxsim_probe.hip && ./maxsim_probe [ndocs]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
         float best = 1e9;
         for (int it = 0; it < 5; ++it) {
             hipEventRecord(a);
-            maxsim_scan_kernel<false, 32, false><<<blocks, kMsThreads>>>(tok, nullptr, (uint32_t)ndocs, T, 64, dim, q, qpk, NQ, nullptr, out, out, true);
+            maxsim_scan_kernel<false, 32, false><<<blocks, kMsThreads>>>(tok, nullptr, (uint32_t)ndocs, T, 64, dim, q, qpk, NQ, nullptr, out, out, true, nullptr);
             hipEventRecord(b);
             CK(hipEventSynchronize(b));
             float ms; hipEventElapsedTime(&ms, a, b);

@@ -33,8 +33,28 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters, float 
                     asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i]) : "v"(t), "v"(b2));
                 } else if (KIND == 2) {  // v_fma_f32
                     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[i]), "v"(b), "v"(a));
-                } else {  // v_pk_fma_f32
+                } else if (KIND == 3) {  // v_pk_fma_f32
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(y[i]) : "v"(y[i]), "v"(b2), "v"(b2));
+                } else if (KIND == 4) {  // the multiplier from an SGPR pair (what maxsim_scan_kernel's query operands are)
+                    f32x2 t;
+                    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "s"(b2), "v"(y[i]));
+                    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i]) : "v"(t), "v"(b2));
+                } else if (KIND == 5) {  // unpacked, the multiplier from an SGPR
+                    float t;
+                    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "s"(b), "v"(x[i]));
+                    asm volatile("v_add_f32 %0, %1, %2" : "=v"(x[i]) : "v"(t), "v"(a));
+                } else {  // KIND 6: packed, SGPR multiplier, four products then four sums (maxsim_group's order)
+                    if ((i & 3) == 0) {
+                        f32x2 t0, t1, t2, t3;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t0) : "s"(b2), "v"(y[i]));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t1) : "s"(b2), "v"(y[i + 1]));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t2) : "s"(b2), "v"(y[i + 2]));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t3) : "s"(b2), "v"(y[i + 3]));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i]) : "v"(t0), "v"(b2));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i + 1]) : "v"(t1), "v"(b2));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i + 2]) : "v"(t2), "v"(b2));
+                        asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y[i + 3]) : "v"(t3), "v"(b2));
+                    }
                 }
             }
     }
@@ -68,5 +88,8 @@ int main() {
     if (run<1>("v_pk_mul_f32 + v_pk_add_f32", 2, 64, out)) return 1;
     if (run<2>("v_fma_f32", 1, 32, out)) return 1;
     if (run<3>("v_pk_fma_f32", 2, 32, out)) return 1;
+    if (run<4>("v_pk_mul_f32 (SGPR) + v_pk_add", 2, 64, out)) return 1;
+    if (run<5>("v_mul_f32 (SGPR) + v_add_f32", 1, 64, out)) return 1;
+    if (run<6>("4 x pk_mul (SGPR), 4 x pk_add", 2, 64, out)) return 1;
     return 0;
 }

@@ -1,10 +1,7 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
-tail -3 gpurun_out/gpu_tests.log
-timeout -k 10 400 python3 tools/bench_maxsim.py > gpurun_out/ms_c4.json 2> gpurun_out/ms_c4.err
-python3 -c "
-import json; d=json.load(open('gpurun_out/ms_c4.json'))
-for k,v in d.items():
-    if isinstance(v,dict): print(k, {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items() if a in ('scan_ms','total_ms','scan_GBps')})
-"
+timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_u8.py -x -q -m gpu -k "small_batch" > gpurun_out/i8s_tests.log 2>&1 || { tail -40 gpurun_out/i8s_tests.log; exit 1; }
+tail -2 gpurun_out/i8s_tests.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_i8s -o i8s -- python3 $GRAFT_REPO_ROOT/tools/run_c2.py i8 10 dot 64 > $GRAFT_REPO_ROOT/gpurun_out/prof_i8s.log 2>&1
+cd $GRAFT_REPO_ROOT && ls gpurun_out/prof_i8s | head; f=$(ls gpurun_out/prof_i8s/*kernel_stats.csv | head -1); head -25 $f | cut -c1-160

@@ -91,6 +91,7 @@ struct innr_tuning {
     long trace = 0;              // diagnostics of the redo paths on stderr (list lengths of the completion pass, ...)
     long no_rows_copy = 0;       // never build the row-major copy: the completion pass re-scores by column gathers (what a full HBM does)
     long i8_slices_per_cu = 0;   // corpus slices (= blocks) per CU and query tile of the int8 filters; 0 = by metric (plan_i8)
+    long i8_no_small = 0;        // never the small-batch int8 kernel (gemm_i8s_filter_kernel): A/B against the 512-query tile
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -101,7 +102,7 @@ static const TuneName kTuneNames[] = {
     {"no_auto_i8", &innr_tuning::no_auto_i8}, {"u8_no_i8", &innr_tuning::u8_no_i8}, {"rescore_all", &innr_tuning::rescore_all},
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
     {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
-    {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu},
+    {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu}, {"i8_no_small", &innr_tuning::i8_no_small},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -2629,7 +2630,22 @@ struct I8Plan {
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
     uint32_t nk;  // K-steps of 64 dimensions of the corpus copy the launch multiplies (the squared-L2 copy has more than the others)
     bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
+    bool small = false;  // gemm_i8s_filter_kernel (<= 64 queries, every wave a slice of its own): nslices waves, tps QUARTER tiles each
 };
+// The small-batch kernel applies to a one-limb MODE 0 launch of at most 64 queries with lists of 128 whose K-step count has an
+// instantiation (even, <= 16: D <= 1024) and whose bounds are SEEDED (its survivors' path is built for a trickle, not for the flood
+// of an unseeded first tile).
+static bool plan_i8_small(const innr_batch* b, I8Plan* p, size_t Q, bool seeded) {
+    if (p->two || Q > (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || p->cap != 768 || !seeded || b->ctx->tune.i8_no_small) return false;
+    const uint32_t nquarter = 4 * p->ntiles;
+    p->small = true;
+    p->Qpad = kI8sBQ;
+    p->nqt = p->qtg = 1;
+    p->nblocks = std::max(1u, std::min((uint32_t)b->ctx->num_cus, (nquarter + kI8sWaves - 1) / kI8sWaves));
+    p->nslices = p->nblocks * kI8sWaves;
+    p->tps = (nquarter + p->nslices - 1) / p->nslices;
+    return true;
+}
 static I8Plan plan_i8(const innr_batch* b, size_t Q, size_t kout, uint32_t kp_override = 0, bool one_limb = false) {
     I8Plan p;
     p.two = !one_limb && (i8_two_limb(b->ctx, kout) || kp_override > 128);  // (collect mode: always the one-limb kernel)
@@ -2675,7 +2691,37 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
         if (two) gemm_i8_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                  \
         else gemm_i8h_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                     \
     } while (0)
-    if constexpr (MODE == 1) {
+    if (p.small) {
+        if constexpr (MODE == 0) {
+            const size_t dyn = i8s_dyn_lds_bytes(p.nk);
+#define INNR_I8S_LAUNCH(NKV)                                                                                                         \
+    do {                                                                                                                            \
+        static bool raised = false;  /* (per instantiation) */                                                                      \
+        if (dyn > 48 * 1024 && !raised) {                                                                                           \
+            INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV>),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                              \
+            raised = true;                                                                                                          \
+        }                                                                                                                           \
+        gemm_i8s_filter_kernel<12, NKV><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                              \
+            corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.tps, qc, c->lists.as<uint64_t>(),                 \
+            c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot);                                   \
+    } while (0)
+            switch (p.nk) {  // (plan_i8_small: even, <= 16, lists of 128 = capacity 768 = R 12)
+                case 2: INNR_I8S_LAUNCH(2); break;
+                case 4: INNR_I8S_LAUNCH(4); break;
+                case 6: INNR_I8S_LAUNCH(6); break;
+                case 8: INNR_I8S_LAUNCH(8); break;
+                case 10: INNR_I8S_LAUNCH(10); break;
+                case 12: INNR_I8S_LAUNCH(12); break;
+                case 14: INNR_I8S_LAUNCH(14); break;
+                default: INNR_I8S_LAUNCH(16); break;
+            }
+#undef INNR_I8S_LAUNCH
+        } else {
+            set_error("internal: the small-batch int8 kernel has no mode %d", MODE);
+            return INNR_E_BAD_ARG;
+        }
+    } else if constexpr (MODE == 1) {
         INNR_I8_LAUNCH(6);
     } else if constexpr (MODE == 2) {  // collect (the completion pass): one-limb kernel, the list geometry plays no part
         gemm_i8h_filter_kernel<6, 2><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);
@@ -2715,7 +2761,10 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
                              uint64_t* d_out_idx, float* d_out_score, uint32_t* nfallback, uint32_t* kept, float* gemm_ms) {
     innr_ctx* c = b->ctx;
     INNR_TRY(ensure_i8_corpus(b));
-    const I8Plan p = plan_i8(b, Q, kout);
+    I8Plan p = plan_i8(b, Q, kout);
+    const size_t kSeedN = seed_prefix_rows(c, true, Q);
+    const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;
+    (void)plan_i8_small(b, &p, Q, seeded);
     INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum, b->alpha, b->offset));
     const float* qc = c->misc.as<float>();
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
@@ -2727,8 +2776,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     // threshold seeding (cf. knn_mfma): the exact top-KP of a 2048-document prefix per query; their KP-th exact score
     // lowered by the query's error bound is a valid chip-wide bound from the first tile on
     const uint32_t* seed = nullptr;
-    const size_t kSeedN = seed_prefix_rows(c, true, Q);
-    if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
+    if (seeded) {
         const uint32_t kseed = c->tune.no_k_rule ? p.KP : (uint32_t)kout;  // (see knn_mfma)
         INNR_TRY(c->seed_idx.ensure(Q * kseed * sizeof(uint64_t)));
         INNR_TRY(c->seed_score.ensure(Q * kseed * sizeof(float) + p.Qpad * sizeof(uint32_t)));
@@ -2913,6 +2961,9 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     const bool direct = pick_kp(4 * kout + 64, 0) <= 256;
     I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? pick_kp(4 * kout + 64, 0) : pick_kp(kout, 16)), collect_kth != nullptr);
     if (l2) p.nk = b->ai8l_nk;
+    const size_t kSeedN = seed_prefix_rows(c, true, Q);
+    const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;
+    if (!collect_kth) (void)plan_i8_small(b, &p, Q, seeded);
     // exact query norms; cosine: 1/||q|| and the normalised copy the filter multiplies; sum and L1 norm of what it multiplies
     INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
     INNR_TRY(c->tmp_norms.ensure(6 * p.Qpad * sizeof(float)));
@@ -2988,8 +3039,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
         return INNR_OK;  // (the caller reads ev[2..3] once it has synchronised)
     }
     const uint32_t* seed = nullptr;
-    const size_t kSeedN = seed_prefix_rows(c, true, Q);
-    if (b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed) {
+    if (seeded) {
         const uint32_t kseed = c->tune.no_k_rule ? p.KP : (uint32_t)kout;  // (see knn_mfma)
         INNR_TRY(c->seed_idx.ensure(Q * kseed * sizeof(uint64_t)));
         INNR_TRY(c->seed_score.ensure(Q * kseed * sizeof(float) + p.Qpad * sizeof(uint32_t)));

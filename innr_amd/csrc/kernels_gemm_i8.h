@@ -1204,4 +1204,259 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
     }
 }
 
+// ---- gemm_i8s_filter_kernel: the one-limb filter for a SMALL query batch (<= 64 queries) ----------------------------------------
+// gemm_i8h_filter_kernel's block tile is 128 corpus rows x 512 queries: a batch below 512 queries pays the matrix work of 512
+// (2.6 ms at ONE query at C2 -- 59 % of the int8 pipe on padding -- where streaming the 7.7 GB copy takes 1.3 ms). Here the roles
+// are swapped: the queries' high limbs (nk x 4 KB: every B fragment of the launch) sit in LDS for the whole kernel, every WAVE
+// streams corpus rows of its own -- QUARTER tiles of 32 rows (row tile q & 3 of tile q >> 2) -- and nothing couples the waves: no
+// LDS stage, no barrier after the prologue, a wave that finishes its survivors stalls nobody. The K-step count is a template
+// parameter and the loop over it fully unrolled, every load plain C (as in maxsim_mfma_tile_kernel): a quarter tile's NK x 2
+// fragments have registers of their own, fragment ks of the NEXT quarter tile is requested as soon as fragment ks of this one has
+// been multiplied, and hipcc's own s_waitcnt vmcnt(N) is then the exact number of younger requests -- a whole quarter tile (NK KB)
+// in flight per wave. (A first version with a four-stage ring, a run-time K loop and hand-issued asm loads was compiled into
+// copies of in-flight registers at every phi; with plain loads in that loop the back-edge made every wait a vmcnt(0).)
+// HBM-bound by design: 4 MFMAs of 32 cycles per 2 KB of fragments. Each wave is a slice of its own (lists, counts:
+// [nblocks * 8][64]); thresholds, slots, the k rule and the list discipline are gemm_i8h_filter_kernel's. Needs seeded bounds
+// (api.hip picks it only then): an unseeded first tile passes all its sites through the survivors' path, four per round trip.
+constexpr int kI8sBQ = 64, kI8sWaves = 8, kI8sSurvCap = 128;
+struct alignas(16) GemmI8sLds {
+    uint32_t cnt[kI8sWaves][kI8sBQ];
+    uint32_t thr[kI8sWaves][kI8sBQ];
+    uint32_t surv[kI8sWaves][kI8sSurvCap][4];  // high limb, corpus row, lane | query column tile << 8
+};
+__host__ __device__ inline size_t i8s_dyn_lds_bytes(uint32_t nk) { return (size_t)nk * 4096; }
+
+template <int R, int NK>
+__global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
+    const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t nquarter /*quarter tiles: 4 * ntiles*/, uint32_t N,
+    size_t Qpad /*= 64*/, uint32_t quarters_per_wave, const float* __restrict__ qc, uint64_t* __restrict__ lists,
+    uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr) {
+    extern __shared__ __attribute__((aligned(16))) char i8s_b[];  // [NK][m 2][ct 2][64 lanes] x 16 B: the high limbs as B fragments
+    __shared__ GemmI8sLds s;
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);
+    constexpr int S = kI8hS;
+    constexpr uint32_t cap = 64 * R, nk = NK;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int half = lane >> 5, C = lane & 31;
+    for (uint32_t idx = threadIdx.x; idx < nk * 256; idx += 64 * kI8sWaves) {
+        const uint32_t l = idx & 63, x = idx >> 6, ct = x & 1, m = (x >> 1) & 1, ks = x >> 2;
+        reinterpret_cast<uint4*>(i8s_b)[idx] =
+            reinterpret_cast<const uint4*>(Bq)[((size_t)(ks * 4 + 2 * m + (l >> 5)) * 2) * Qpad + ct * 32 + (l & 31)];
+    }
+    s.cnt[w][lane] = 0;
+    s.thr[w][lane] = 0;
+    __syncthreads();  // (the only barrier)
+
+    const uint32_t slice = blockIdx.x * kI8sWaves + (uint32_t)wu;
+    uint32_t q0 = slice * quarters_per_wave, q1 = q0 + quarters_per_wave;
+    if (q1 > nquarter) q1 = nquarter;
+    if (q0 > q1) q0 = q1;
+    uint64_t* my_lists = lists + (size_t)slice * Qpad * cap;
+    float Aj[2], Bj[2], invAj[2];
+    int32_t lob[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const size_t q = 32 * ct + C;
+        Aj[ct] = qc[q];
+        Bj[ct] = qc[Qpad + q];
+        invAj[ct] = qc[2 * Qpad + q];
+        lob[ct] = __float_as_int(qc[4 * Qpad + q]);
+    }
+    // fragment m of quarter tile q at K-step ks: 16 B of row C of row tile q & 3, k-group 2 m + half
+    const i32x4_t* const frag0 = reinterpret_cast<const i32x4_t*>(Ai8) + (size_t)half * 128 + C;
+    auto frag = [&](uint32_t q, int ks, int m) -> i32x4_t {
+        return frag0[(((size_t)(q >> 2) * nk + (uint32_t)ks) * 4 + 2u * (uint32_t)m) * 128 + (q & 3u) * 32u];
+    };
+    i32x4_t A[NK][2];
+    if (q0 < q1) {
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            A[ks][0] = frag(q0, ks, 0);
+            A[ks][1] = frag(q0, ks, 1);
+        }
+    }
+    uint32_t ns = 0;
+    for (uint32_t q = q0; q < q1; ++q) {
+        // the chip-wide bounds of this quarter tile, requested before its successor's fragments: the oldest request in flight when
+        // the epilogue needs it
+        uint32_t tg_cur[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) tg_cur[ct] = __hip_atomic_load(gthr + 32 * ct + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t qn = q + 1 < q1 ? q + 1 : q;  // (the last quarter tile requests its own fragments again: no branch in the K loop)
+        i32x16_t acc[1][2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[0][ct][g] = 0;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const i32x4_t* bl = reinterpret_cast<const i32x4_t*>(i8s_b) + (size_t)ks * 256 + lane;
+            const i32x4_t b00 = bl[0], b01 = bl[64], b10 = bl[128], b11 = bl[192];  // [m][ct]
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][0], b00, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][0], b01, acc[0][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][1], b10, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][1], b11, acc[0][1], 0, 0, 0);
+            A[ks][0] = frag(qn, ks, 0);
+            A[ks][1] = frag(qn, ks, 1);
+        }
+        const uint32_t h = q;  // (the epilogue's name for the unit it finishes)
+        // ---------------- epilogue of quarter tile h: two queries per lane, 16 corpus rows each ----------------
+        const uint32_t tb = (h >> 2) * 128u, rt0 = h & 3u;
+        uint32_t thr[2];
+        int32_t Tint[2], Thi[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const uint32_t tl = __hip_atomic_load(&s.thr[wu][32 * ct + C], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            thr[ct] = tl > tg_cur[ct] ? tl : tg_cur[ct];
+            Tint[ct] = INT32_MIN;
+            Thi[ct] = INT32_MIN;
+            if (thr[ct] != 0u) {  // (as in gemm_i8h_filter_kernel)
+                const float x = (ord_f32(thr[ct]) - Bj[ct]) * invAj[ct];
+                if (x >= 2147483520.0f || thr[ct] == 0xFFFFFFFFu) {
+                    Tint[ct] = INT32_MAX;
+                    Thi[ct] = INT32_MAX;
+                } else if (x > -2.0e9f) {
+                    Tint[ct] = (int32_t)__builtin_floorf(x) - 2 - (int32_t)(fabsf(x) * 4.8e-7f);
+                    const long long d = (long long)Tint[ct] - (long long)lob[ct];
+                    Thi[ct] = d < -2147483000ll ? INT32_MIN : (int32_t)(d >> S);
+                }
+            }
+        }
+        bool hit[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            int32_t m4 = INT32_MIN;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) m4 = m4 > acc[0][ct][g] ? m4 : acc[0][ct][g];
+            hit[ct] = m4 >= Thi[ct];
+        }
+        if (!__any(hit[0] || hit[1])) continue;
+        bool admitted[2] = {false, false};
+        // finish the queued survivors, four per memory round trip (gemm_i8h_filter_kernel's flush: 16 lanes per survivor)
+        auto flush = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            constexpr int PER = 4, LPS = 64 / PER, CPL = 48 / LPS;
+            const int g_mine = lane / LPS, l16 = lane % LPS;
+            for (uint32_t e0 = 0; e0 < ns; e0 += PER) {
+                const uint32_t nb = ns - e0 < (uint32_t)PER ? ns - e0 : (uint32_t)PER;
+                const uint32_t em = e0 + ((uint32_t)g_mine < nb ? (uint32_t)g_mine : 0u);
+                const uint32_t hi_m = s.surv[wu][em][0], row_m = s.surv[wu][em][1], lc_m = s.surv[wu][em][2];
+                const uint32_t rr = row_m & 127u;
+                const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)(row_m >> 7) * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
+                const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (32 * ((lc_m >> 8) & 1u) + (lc_m & 31u));
+                int32_t part = 0;
+                for (uint32_t c0 = 0; c0 < nk * 4; c0 += 48) {
+                    uint4 x[CPL], y[CPL];
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) {
+                        const uint32_t c = c0 + (uint32_t)l16 + (uint32_t)LPS * (uint32_t)t;
+                        const bool on = (uint32_t)g_mine < nb && c < nk * 4;
+                        x[t] = on ? pa[(size_t)c * 128] : uint4{0u, 0u, 0u, 0u};
+                        y[t] = on ? pb[(size_t)c * 2 * Qpad] : uint4{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int t = 0; t < CPL; ++t) {
+                        part = __builtin_amdgcn_sdot4((int)x[t].x, (int)y[t].x, part, false);
+                        part = __builtin_amdgcn_sdot4((int)x[t].y, (int)y[t].y, part, false);
+                        part = __builtin_amdgcn_sdot4((int)x[t].z, (int)y[t].z, part, false);
+                        part = __builtin_amdgcn_sdot4((int)x[t].w, (int)y[t].w, part, false);
+                    }
+                }
+#pragma unroll
+                for (int off = LPS / 2; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+                for (uint32_t g = 0; g < nb; ++g) {
+                    const int32_t lo = __builtin_amdgcn_readlane(part, LPS * (int)g);
+                    const int32_t hiL = (int32_t)__builtin_amdgcn_readlane((int)hi_m, LPS * (int)g);
+                    const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)row_m, LPS * (int)g);
+                    const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)lc_m, LPS * (int)g);
+                    const int L = (int)(lc & 63u);
+                    const bool c1 = ((lc >> 8) & 1u) != 0;
+                    const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)lo);
+                    if (lane == L && V >= (c1 ? Tint[1] : Tint[0])) {
+                        const uint32_t o = f32_ord(__builtin_fmaf(c1 ? Aj[1] : Aj[0], (float)V, c1 ? Bj[1] : Bj[0]));
+                        if (o >= (c1 ? thr[1] : thr[0]) && i < N) {
+                            const int ql = 32 * (c1 ? 1 : 0) + C;
+                            const bool pub = (i & (kI8hPubEvery - 1)) == 0;
+                            admitted[0] = admitted[0] || (pub && !c1);
+                            admitted[1] = admitted[1] || (pub && c1);
+                            cand_append(my_lists + (size_t)ql * cap, &s.cnt[wu][ql], cap, cand_make(o, i), errflag);
+                            gthr_raise(gslots + (size_t)ql * (kSlotMul * KP), kSlotMul * KP, o, i);
+                        }
+                    }
+                }
+            }
+            ns = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            if (!__any(hit[ct])) continue;
+#pragma unroll
+            for (int r2 = 0; r2 < 1; ++r2)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int32_t hi = acc[r2][ct][g];
+                    const bool surv = hit[ct] && hi >= Thi[ct];
+                    const unsigned long long mm = __ballot(surv);
+                    if (!mm) continue;
+                    const uint32_t nm = (uint32_t)__popcll(mm);
+                    if (ns + nm > (uint32_t)kI8sSurvCap) flush();
+                    if (surv) {
+                        const uint32_t slot = ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                        s.surv[wu][slot][0] = (uint32_t)hi;
+                        s.surv[wu][slot][1] = tb + 4u * ((uint32_t)(g & 3) + 8u * (uint32_t)(g >> 2) + 4u * (uint32_t)half) + rt0 + (uint32_t)r2;
+                        s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
+                    }
+                    ns += nm;
+                }
+        }
+        flush();
+        // re-derive the chip-wide bounds that asked for it; compact lists that run short of room
+        unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            unsigned long long m = admitted_by[ct];
+            m = (m | (m >> 32)) & 0xffffffffull;
+            while (m) {
+                const int L = __builtin_ctzll(m);
+                m &= m - 1;
+                const size_t qg = 32 * ct + L;  // wave-uniform
+                gthr_publish_select<(kSlotMul * (16 * R - 64) + 63) / 64>(gslots + qg * (size_t)(kSlotMul * KP), gthr + qg, KP, lane, kk, kmargin[qg]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c = __hip_atomic_load(&s.cnt[wu][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned long long need = __ballot(c > cap - 32u);  // (a quarter tile appends at most 32 rows to one query's list)
+        while (need) {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)j * cap, cj, KP, &t);
+            if (lane == 0) {
+                s.cnt[wu][j] = keep;
+                s.thr[wu][j] = t;
+                if (t > __hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    __hip_atomic_fetch_max(&gthr[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        const uint32_t c = __hip_atomic_load(&s.cnt[wu][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        unsigned long long need = __ballot(c > KP);
+        uint32_t mine = c;
+        while (need) {
+            const int j = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+            uint32_t t;
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)j * cap, cj, KP, &t);
+            if (lane == j) mine = keep;
+        }
+        counts[(size_t)slice * Qpad + lane] = mine;
+    }
+}
+
 }  // namespace innr

@@ -207,3 +207,26 @@ def test_int8_filter_squared_l2(B, innr, n, dim, nq, k):
     _check_knn(B, innr, "l2", far, oracle.from_rows(far), (qs + np.float32(50.0)).astype(np.float32), k, innr.KNN_MFMA_I8)
     _check_knn(B, innr, "l2", vb, oracle.from_rows(rows), (qs * np.float32(40.0)).astype(np.float32), k, innr.KNN_MFMA_I8)
     _check_knn(B, innr, "dot", vb, oracle.from_rows(rows), qs, min(k, 48), innr.KNN_MFMA_I8)  # (the dot copy beside it, same range)
+
+
+@pytest.mark.parametrize("dim,nq", [(64, 64), (200, 5), (300, 1), (500, 3), (600, 2), (768, 4), (1000, 2)])
+def test_int8_small_batch_kernel_every_k_step_count(B, innr, dim, nq, ctx_option):
+    """gemm_i8s_filter_kernel (at most 64 queries on a corpus large enough for seeded bounds: every wave streams quarter tiles of its
+    own, the queries' high limbs in LDS): one instantiation per K-step count 2, 4, ... 16 -- dot / cosine / squared L2 (whose copy
+    has D + R + 1 dimensions: the next count up for some of these) against the oracle, and against the 512-query-tile kernel
+    (option i8_no_small) bit for bit."""
+    n = 140_000  # >= 32 x 4096 rows: seeded
+    rows, _ = _corpus(n, dim, 5, uniform=True)
+    rows = (rows * (1.0 + 0.5 * np.sin(np.arange(n, dtype=np.float32)))[:, None]).astype(np.float32)
+    data = oracle.from_rows(rows)
+    qs = _queries(nq, dim, 99, uniform=True)
+    vb = B.VerticalBatch.from_rows(rows)
+    for metric, fn in (("dot", B.batch_knn_dot_multi), ("cos", B.batch_knn_cosine_multi), ("l2", B.batch_knn_multi)):
+        _check_knn(B, innr, metric, vb, data, qs, 10, innr.KNN_MFMA_I8)
+        st = innr.KnnStats()
+        i1, s1 = fn(qs, vb, 10, engine=innr.KNN_MFMA_I8, stats=st)
+        assert st.engine == innr.KNN_MFMA_I8 and st.queries_fallback <= 1
+        ctx_option("i8_no_small", 1)
+        i2, s2 = fn(qs, vb, 10, engine=innr.KNN_MFMA_I8)
+        ctx_option("i8_no_small", 0)
+        assert np.array_equal(i1, i2) and bits_equal(s1, s2)

@@ -153,6 +153,25 @@ def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_
     assert st.queries_fallback <= max(2, nq // 4), st.queries_fallback
 
 
+@pytest.mark.parametrize("nq,dim", [(1, 128), (9, 96), (64, 200)])
+def test_batch_knn_u8_small_batch_kernel(S, innr, nq, dim, ctx_option):
+    """at most 64 queries, lists of 128 (k = 100) and a corpus large enough for seeded bounds: the int8 engine runs
+    gemm_i8s_filter_kernel (one wave = one slice, queries in LDS); same answers as the oracle and as the 512-query-tile kernel"""
+    n, k, alpha, offset = 140_000, 100, 2.0, -1.0
+    codes = _codes(n, dim, 11, alpha, offset)
+    qc = S.QuantizedCorpus.from_codes(codes, n, dim, S.QuantizationParams(alpha, offset))
+    qs = oracle.generate_uniform(nq, dim, 321)
+    st = innr.KnnStats()
+    idx, sc = qc.knn_multi(qs, k, engine=innr.KNN_MFMA_I8, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8
+    for j in range(nq):
+        oi, os_ = _oracle_knn(qs[j], codes, alpha, offset, k)
+        assert same_knn("dot", idx[j], sc[j], oi, os_), (j, idx[j], oi)
+    ctx_option("i8_no_small", 1)
+    idx2, sc2 = qc.knn_multi(qs, k, engine=innr.KNN_MFMA_I8)
+    assert np.array_equal(idx, idx2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+
+
 def test_u8_edge_cases(S, innr):
     p = S.QuantizationParams.from_range(0.0, 1.0)
     assert S.batch_knn_u8([1.0], [], p, 5) == []  # scalar.rs:601-605

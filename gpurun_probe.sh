@@ -1,7 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_u8.py -x -q -m gpu -k "small_batch" > gpurun_out/i8s_tests.log 2>&1 || { tail -40 gpurun_out/i8s_tests.log; exit 1; }
-tail -2 gpurun_out/i8s_tests.log
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_i8s -o i8s -- python3 $GRAFT_REPO_ROOT/tools/run_c2.py i8 10 dot 64 > $GRAFT_REPO_ROOT/gpurun_out/prof_i8s.log 2>&1
-cd $GRAFT_REPO_ROOT && ls gpurun_out/prof_i8s | head; f=$(ls gpurun_out/prof_i8s/*kernel_stats.csv | head -1); head -25 $f | cut -c1-160
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+for a in "i8 10 dot 1" "i8 10 dot 8" "i8 10 dot 64" "i8 10 l2 64" "i8 10 dot 1024" "i8 10 dot 128" "bf16 10 dot 64"; do timeout -k 10 300 python3 tools/run_c2.py $a; done > gpurun_out/i8s_c2.log 2>&1
+grep C2 gpurun_out/i8s_c2.log

@@ -693,7 +693,7 @@ static innr_status prep_queries(innr_batch* b, const GemmPlan& p, const float* d
     transpose_queries_kernel<<<grid, 256, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, c->q_kmajor.as<float>(),
                                                           p.Qpad, (uint32_t)b->Dpad);
     INNR_HIP_CHECK(hipGetLastError());
-    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D,
+    query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D,
                                                                        c->q_norm.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     if (cos) {
@@ -1342,7 +1342,7 @@ static innr_status knn_mfma(innr_batch* b, int metric, const float* dQ, size_t Q
         INNR_TRY(knn_complete(b, metric, dQ, redo, kout, d_out_idx, d_out_score, &still, gemm_ms));
         redo.swap(still);
         if (cos || !redo.empty()) {  // (the completion pass used the query workspace: the redo below reads the norms again)
-            query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+            query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
             INNR_HIP_CHECK(hipGetLastError());
         }
     }
@@ -1720,7 +1720,7 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
         INNR_TRY(c->misc.ensure((Q + 1) * sizeof(uint32_t) + 64));
         INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
         if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
-        query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+        query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
                                                                            c->q_norm.as<float>());
         INNR_HIP_CHECK(hipGetLastError());
         uint32_t* bad = c->flags.as<uint32_t>() + 65;
@@ -1763,7 +1763,7 @@ innr_status innr_batch_rerank_dev(innr_batch* b, int metric, const float* d_quer
     INNR_TRY(c->misc.ensure(Q * sizeof(uint32_t) + 64));
     INNR_HIP_CHECK(hipMemsetAsync(c->flags.p, 0, 4096, c->stream));
     if (metric == INNR_METRIC_COSINE) INNR_TRY(ensure_norms(b));
-    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+    query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
                                                                        c->q_norm.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     uint32_t* bad = c->flags.as<uint32_t>() + 65;
@@ -2061,7 +2061,7 @@ innr_status innr_batch_knn_dev(innr_batch* b, int metric, const float* d_queries
     if (metric == INNR_METRIC_COSINE) {
         INNR_TRY(ensure_norms(b));
         INNR_TRY(c->q_norm.ensure(Q * sizeof(float)));
-        query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
+        query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(d_queries, (uint32_t)Q, (uint32_t)D, D,
                                                                            c->q_norm.as<float>());
         INNR_HIP_CHECK(hipGetLastError());
         dQn = c->q_norm.as<float>();
@@ -2973,7 +2973,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     float* cq = invq + p.Qpad;  // squared L2: C_j - |q_j|^2, C_j = (|q_j| + max|v|)^2 (the score space C_j - distance of the f32 engine)
     float* Cj = cq + p.Qpad;
     float* ql1q = Cj + p.Qpad;  // ... and the L1 norm of the query itself
-    query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+    query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
     INNR_HIP_CHECK(hipGetLastError());
     const float* Qp = dQ;
     if (cos) {
@@ -2988,13 +2988,13 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
         f32i8_l2_queries_kernel<<<(unsigned)((Q * Dq + 255) / 256), 256, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->i8l_R, w1, w2,
                                                                                      c->q_hat.as<float>());
         INNR_HIP_CHECK(hipGetLastError());
-        f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, nullptr, nullptr, qsum, ql1q);
+        f32i8_query_prep_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, nullptr, nullptr, qsum, ql1q);
         INNR_HIP_CHECK(hipGetLastError());
         l2_query_consts_kernel<<<(unsigned)((p.Qpad + 255) / 256), 256, 0, c->stream>>>(c->q_norm.as<float>(), p.Qpad, Q, b->max_norm, cq, Cj);
         INNR_HIP_CHECK(hipGetLastError());
         Qp = c->q_hat.as<float>();
     }
-    f32i8_query_prep_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(l2 ? Qp : dQ, (uint32_t)Q, (uint32_t)Dq, cos ? invq : nullptr,
+    f32i8_query_prep_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(l2 ? Qp : dQ, (uint32_t)Q, (uint32_t)Dq, cos ? invq : nullptr,
                                                                             cos ? c->q_hat.as<float>() : nullptr, qsum, ql1);
     INNR_HIP_CHECK(hipGetLastError());
     INNR_TRY(prep_queries_i8(b, p, Qp, Q, qsum, alpha, offset, Dq));
@@ -3098,7 +3098,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     }
     if (!redo.empty()) {  // one batch on the f32 GEMM engine (its own proof, completion pass and the exact engine behind it)
         if (cos) {  // (the completion pass used the query workspace: the exact norms of the whole batch again)
-            query_norms_kernel<<<(unsigned)((Q + 63) / 64), 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
+            query_norms_kernel<<<(unsigned)Q, 64, 0, c->stream>>>(dQ, (uint32_t)Q, (uint32_t)b->D, b->D, c->q_norm.as<float>());
             INNR_HIP_CHECK(hipGetLastError());
         }
         INNR_TRY(redo_batch(b, metric, dQ, cos ? c->q_norm.as<float>() : nullptr, redo, kout, d_out_idx, d_out_score,

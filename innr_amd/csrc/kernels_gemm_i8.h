@@ -168,20 +168,29 @@ __global__ __launch_bounds__(256) void pack_corpus_f32_i8_kernel(const float* __
 }
 
 // queries of the f32-corpus filter: (cosine: normalised copy,) sum and L1 norm per query
-__global__ void f32i8_query_prep_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, const float* __restrict__ qscale,
-                                        float* __restrict__ qhat, float* __restrict__ qsum, float* __restrict__ ql1) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void f32i8_query_prep_kernel(const float* __restrict__ Qm, uint32_t Q, uint32_t D, const float* __restrict__ qscale,
+                                                              float* __restrict__ qhat, float* __restrict__ qsum, float* __restrict__ ql1) {
+    // one wave per query (grid = Q); the sums are order-free (the bound below covers any order of D - 1 additions)
+    const uint32_t j = blockIdx.x;
     if (j >= Q) return;
+    const int lane = threadIdx.x;
     const float sc = qscale ? qscale[j] : 1.0f;
     float s1 = 0.0f, l1 = 0.0f;
-    for (uint32_t d = 0; d < D; ++d) {
+    for (uint32_t d = lane; d < D; d += 64) {
         const float x = Qm[(size_t)j * D + d] * sc;
         if (qhat) qhat[(size_t)j * D + d] = x;
         s1 += x;
         l1 += fabsf(x);
     }
-    qsum[j] = s1;
-    ql1[j] = l1 * (1.0f + 1.2e-7f * (float)D);  // an upper bound of the true L1 norm despite the rounding of the sum
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        l1 += __shfl_xor(l1, off, 64);
+    }
+    if (lane == 0) {
+        qsum[j] = s1;
+        ql1[j] = l1 * (1.0f + 1.2e-7f * (float)D);  // an upper bound of the true L1 norm despite the rounding of the sum
+    }
 }
 
 // the proof's bound per query: the int8 engine's own share (qc[3]: the query's quantisation, float rounding) + the corpus

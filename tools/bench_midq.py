@@ -28,7 +28,7 @@ for nq in qlist:
     B.batch_knn_dot_multi(q, vb, 10, engine=KNN_AUTO, stats=st)
     auto = st.engine
     for engine in (KNN_EXACT, KNN_MFMA, KNN_MFMA_I8, KNN_MFMA_BF16, KNN_AUTO):
-        if (engine == KNN_EXACT and nq > 64) or (engine in (KNN_MFMA_I8, KNN_MFMA_BF16) and nq < 8) or (engine == KNN_MFMA and nq > 512):
+        if (engine == KNN_EXACT and nq > 64) or (engine == KNN_MFMA_BF16 and nq < 8) or (engine == KNN_MFMA and nq > 512):
             continue
         best, redo = 1e9, 0
         for it in range(3):

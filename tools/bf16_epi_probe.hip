@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&V, ldN * D * 4)); CK(hipMalloc(&Qm, Q * D * 4));
     CK(hipMalloc(&Ab, units * 16)); CK(hipMalloc(&Bb, (size_t)nk * 4 * Qpad * 16));
     CK(hipMalloc(&lists, (size_t)ns * Qpad * cap * 8)); CK(hipMalloc(&counts, (size_t)ns * Qpad * 4));
-    CK(hipMalloc(&gs, (Qpad * kSlotMul * KP + Qpad) * 4)); CK(hipMalloc(&err, 4096));
+    CK(hipMalloc(&gs, (Qpad * kSlotMul * KP + 2 * Qpad) * 4 /* slots, bounds, k-rule margins */)); CK(hipMalloc(&err, 4096));
     generate_pdx_kernel<1><<<dim3((unsigned)((ldN / 4 + 255) / 256), (unsigned)D), 256>>>(V, ldN, (uint32_t)N, (uint32_t)D, 0, 0);
     gen_rows<<<(unsigned)((Q * D + 255) / 256), 256>>>(Qm, (uint32_t)Q, (uint32_t)D, 0xBE7C);
     pack_corpus_bf16_kernel<<<(unsigned)((units + 255) / 256), 256>>>(V, ldN, (uint32_t)N, (uint32_t)D, nk, units, (uint4*)Ab);
@@ -44,10 +44,10 @@ int main(int argc, char** argv) {
     CK(hipFree(V));
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int it = 0; it < 4; ++it) {
-        if (it == 0) CK(hipMemset(gs, 0, (Qpad * kSlotMul * KP + Qpad) * 4));
+        if (it == 0) CK(hipMemset(gs, 0, (Qpad * kSlotMul * KP + 2 * Qpad) * 4 /* slots, bounds, k-rule margins */));
         CK(hipMemset(err, 0, 4096));
         hipEventRecord(a);
-        gemm_bf16_filter_kernel<PROBE_R, 0><<<nqt * ns, 64 * kBfWaves>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, err, gs,
+        gemm_bf16_filter_kernel<PROBE_R, 0><<<nqt * ns, 64 * kBfWaves>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, 0u /* k rule off */, err, gs,
                                                                       gs + Qpad * kSlotMul * KP, nullptr, 0);
         hipEventRecord(b); CK(hipEventSynchronize(b));
         float ms; hipEventElapsedTime(&ms, a, b);

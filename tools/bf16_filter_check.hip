@@ -39,7 +39,7 @@ static int layout_test(size_t N, size_t D, size_t Q) {
     pack_corpus_bf16_kernel<<<(unsigned)((aunits + 255) / 256), 256>>>(dV, ldN, (uint32_t)N, (uint32_t)D, nk, aunits, (uint4*)Ab);
     pack_queries_bf16_kernel<<<(unsigned)(((size_t)nk * 4 * Qpad + 255) / 256), 256>>>(dQ, (uint32_t)Q, (uint32_t)D, nk, (uint32_t)Qpad, (uint4*)Bb);
     const uint32_t ns = 8, tps = (ntiles + ns - 1) / ns;
-    gemm_bf16_filter_kernel<6, 1><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, nullptr, nullptr, 32, err, nullptr,
+    gemm_bf16_filter_kernel<6, 1><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, nullptr, nullptr, 32, 0u, err, nullptr,
                                                      nullptr, dump, ldN);
     CK(hipDeviceSynchronize());
     std::vector<float> out(Qpad * ldN);
@@ -70,7 +70,7 @@ static int speed_test(size_t N, int KPsel) {
     const size_t aunits = (size_t)ntiles * nk * 512;
     CK(hipMalloc(&dV, ldN * D * 4)); CK(hipMalloc(&dQ, Q * D * 4)); CK(hipMalloc(&Ab, aunits * 16)); CK(hipMalloc(&Bb, (size_t)nk * 4 * Qpad * 16));
     CK(hipMalloc(&lists, (size_t)ns * Qpad * cap * 8)); CK(hipMalloc(&counts, (size_t)ns * Qpad * 4));
-    const size_t gwords = Qpad * (size_t)kSlotMul * KP + Qpad;
+    const size_t gwords = Qpad * (size_t)kSlotMul * KP + 2 * Qpad;  // slots, bounds, k-rule margins
     CK(hipMalloc(&gs, gwords * 4)); CK(hipMalloc(&err, 4096)); CK(hipMemset(err, 0, 4096));
     generate_pdx_kernel<1><<<dim3((unsigned)((ldN / 4 + 255) / 256), (unsigned)D), 256>>>(dV, ldN, (uint32_t)N, (uint32_t)D, 0, 0);
     std::vector<float> Qm(Q * D); srand(3); for (auto& x : Qm) x = (float)rand() / RAND_MAX * 2 - 1;
@@ -85,8 +85,8 @@ static int speed_test(size_t N, int KPsel) {
     for (int it = 0; it < 4; ++it) {
         if (!(getenv("PROBE_KEEP") && it > 0)) CK(hipMemset(gs, 0, gwords * 4));  // PROBE_KEEP=1: later launches start from the final bounds
         CK(hipEventRecord(a));
-        if (KP == 32) gemm_bf16_filter_kernel<6, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
-        else gemm_bf16_filter_kernel<12, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
+        if (KP == 32) gemm_bf16_filter_kernel<6, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, 0u /* k rule off */, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
+        else gemm_bf16_filter_kernel<12, 0><<<nqt * ns, 512>>>(Ab, Bb, ntiles, (uint32_t)N, nk, Qpad, nqt, 1, tps, lists, counts, KP, 0u /* k rule off */, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     uint64_t* lists; uint32_t *counts, *gs, *err;
     CK(hipMalloc(&V, ldN * D * 4)); CK(hipMalloc(&Qt, D * Qpad * 4));
     CK(hipMalloc(&lists, (size_t)ns * Qpad * cap * 8)); CK(hipMalloc(&counts, (size_t)ns * Qpad * 4));
-    CK(hipMalloc(&gs, (Qpad * kSlotMul * KP + Qpad) * 4)); CK(hipMalloc(&err, 4096));
+    CK(hipMalloc(&gs, (Qpad * kSlotMul * KP + 2 * Qpad) * 4 /* slots, bounds, k-rule margins */)); CK(hipMalloc(&err, 4096));
     generate_pdx_kernel<1><<<dim3((unsigned)((ldN / 4 + 255) / 256), (unsigned)D), 256>>>(V, ldN, (uint32_t)N, (uint32_t)D, 0, 0);
     generate_pdx_kernel<1><<<dim3((unsigned)((Qpad / 4 + 255) / 256), (unsigned)D), 256>>>(Qt, Qpad, (uint32_t)Q, (uint32_t)D, 0xBE7C, 0);
     CK(hipMemset(err, 0, 4096));
@@ -36,11 +36,11 @@ int main(int argc, char** argv) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9;
     for (int it = 0; it < 4; ++it) {
-        if (!(getenv("PROBE_KEEP") && it > 0)) CK(hipMemset(gs, 0, (Qpad * kSlotMul * KP + Qpad) * 4));  // PROBE_KEEP=1: later launches start from the final thresholds (perfect seeding)
+        if (!(getenv("PROBE_KEEP") && it > 0)) CK(hipMemset(gs, 0, (Qpad * kSlotMul * KP + 2 * Qpad) * 4 /* slots, bounds, k-rule margins */));  // PROBE_KEEP=1: later launches start from the final thresholds (perfect seeding)
         if (getenv("PROBE_KEEP") && it == 3) CK(hipMemset(err, 0, 4096));  // counters of the last (perfectly seeded) launch only
         hipEventRecord(a);
         gemm_filter_kernel<kGemmDot, PROBE_R, 0, WAVES><<<nqt * ns, 64 * WAVES>>>(V, ldN, (uint32_t)N, (uint32_t)D, Qt, Qpad, nqt, 1, tps, nullptr, nullptr,
-                                                                       1.0f, lists, counts, KP, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
+                                                                       1.0f, lists, counts, KP, 0u /* k rule off */, err, gs, gs + Qpad * kSlotMul * KP, nullptr, 0);
         hipEventRecord(b); CK(hipEventSynchronize(b));
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;

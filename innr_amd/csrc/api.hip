@@ -92,6 +92,7 @@ struct innr_tuning {
     long no_rows_copy = 0;       // never build the row-major copy: the completion pass re-scores by column gathers (what a full HBM does)
     long i8_slices_per_cu = 0;   // corpus slices (= blocks) per CU and query tile of the int8 filters; 0 = by metric (plan_i8)
     long i8_no_small = 0;        // never the small-batch int8 kernel (gemm_i8s_filter_kernel): A/B against the 512-query tile
+    long i8_no_small4 = 0;       // ... never its four-column-tile form (65 .. 128 queries)
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -103,6 +104,7 @@ static const TuneName kTuneNames[] = {
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
     {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
     {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu}, {"i8_no_small", &innr_tuning::i8_no_small},
+    {"i8_no_small4", &innr_tuning::i8_no_small4},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -2630,16 +2632,19 @@ struct I8Plan {
     uint32_t nqt, qtg, nslices, tps, KP, cap, nblocks, ntiles;
     uint32_t nk;  // K-steps of 64 dimensions of the corpus copy the launch multiplies (the squared-L2 copy has more than the others)
     bool two;  // both limbs on the matrix pipe (256-query tiles) instead of one limb + fix-up (512-query tiles)
-    bool small = false;  // gemm_i8s_filter_kernel (<= 64 queries, every wave a slice of its own): nslices waves, tps QUARTER tiles each
+    bool small = false;  // gemm_i8s_filter_kernel (<= 128 queries, every wave a slice of its own): nslices waves, tps QUARTER tiles each
+    uint32_t small_ct = 2;  // ... its column tiles of 32 queries per wave: 2 (<= 64 queries) or 4
 };
-// The small-batch kernel applies to a one-limb MODE 0 launch of at most 64 queries with lists of 128 whose K-step count has an
-// instantiation (even, <= 16: D <= 1024) and whose bounds are SEEDED (its survivors' path is built for a trickle, not for the flood
-// of an unseeded first tile).
+// The small-batch kernel applies to a one-limb MODE 0 launch of at most 128 queries with lists of 128 whose K-step count has an
+// instantiation (even, <= 16: D <= 1024; the four-column-tile form for 65 .. 128 queries: 8 .. 16) and whose bounds are SEEDED (its
+// survivors' path is built for a trickle, not for the flood of an unseeded first tile).
 static bool plan_i8_small(const innr_batch* b, I8Plan* p, size_t Q, bool seeded) {
-    if (p->two || Q > (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || p->cap != 768 || !seeded || b->ctx->tune.i8_no_small) return false;
+    if (p->two || Q > 2 * (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || p->cap != 768 || !seeded || b->ctx->tune.i8_no_small) return false;
+    if (Q > (size_t)kI8sBQ && (p->nk < 8 || b->ctx->tune.i8_no_small4)) return false;
     const uint32_t nquarter = 4 * p->ntiles;
     p->small = true;
-    p->Qpad = kI8sBQ;
+    p->small_ct = Q > (size_t)kI8sBQ ? 4u : 2u;
+    p->Qpad = 32 * p->small_ct;
     p->nqt = p->qtg = 1;
     p->nblocks = std::max(1u, std::min((uint32_t)b->ctx->num_cus, (nquarter + kI8sWaves - 1) / kI8sWaves));
     p->nslices = p->nblocks * kI8sWaves;
@@ -2693,28 +2698,38 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     } while (0)
     if (p.small) {
         if constexpr (MODE == 0) {
-            const size_t dyn = i8s_dyn_lds_bytes(p.nk);
-#define INNR_I8S_LAUNCH(NKV)                                                                                                         \
+            const size_t dyn = i8s_dyn_lds_bytes(p.nk, p.small_ct);
+#define INNR_I8S_LAUNCH(NKV, CTV)                                                                                                    \
     do {                                                                                                                            \
         static bool raised = false;  /* (per instantiation) */                                                                      \
         if (dyn > 48 * 1024 && !raised) {                                                                                           \
-            INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV>),                      \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                              \
+            INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV, CTV>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8s_dyn_lds_bytes(NKV, CTV)));      \
             raised = true;                                                                                                          \
         }                                                                                                                           \
-        gemm_i8s_filter_kernel<12, NKV><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                              \
+        gemm_i8s_filter_kernel<12, NKV, CTV><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                         \
             corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.tps, qc, c->lists.as<uint64_t>(),                 \
             c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot);                                   \
     } while (0)
-            switch (p.nk) {  // (plan_i8_small: even, <= 16, lists of 128 = capacity 768 = R 12)
-                case 2: INNR_I8S_LAUNCH(2); break;
-                case 4: INNR_I8S_LAUNCH(4); break;
-                case 6: INNR_I8S_LAUNCH(6); break;
-                case 8: INNR_I8S_LAUNCH(8); break;
-                case 10: INNR_I8S_LAUNCH(10); break;
-                case 12: INNR_I8S_LAUNCH(12); break;
-                case 14: INNR_I8S_LAUNCH(14); break;
-                default: INNR_I8S_LAUNCH(16); break;
+            if (p.small_ct == 4) {
+                switch (p.nk) {  // (plan_i8_small: even, 8 .. 16)
+                    case 8: INNR_I8S_LAUNCH(8, 4); break;
+                    case 10: INNR_I8S_LAUNCH(10, 4); break;
+                    case 12: INNR_I8S_LAUNCH(12, 4); break;
+                    case 14: INNR_I8S_LAUNCH(14, 4); break;
+                    default: INNR_I8S_LAUNCH(16, 4); break;
+                }
+            } else {
+                switch (p.nk) {  // (plan_i8_small: even, <= 16, lists of 128 = capacity 768 = R 12)
+                    case 2: INNR_I8S_LAUNCH(2, 2); break;
+                    case 4: INNR_I8S_LAUNCH(4, 2); break;
+                    case 6: INNR_I8S_LAUNCH(6, 2); break;
+                    case 8: INNR_I8S_LAUNCH(8, 2); break;
+                    case 10: INNR_I8S_LAUNCH(10, 2); break;
+                    case 12: INNR_I8S_LAUNCH(12, 2); break;
+                    case 14: INNR_I8S_LAUNCH(14, 2); break;
+                    default: INNR_I8S_LAUNCH(16, 2); break;
+                }
             }
 #undef INNR_I8S_LAUNCH
         } else {

@@ -1227,34 +1227,48 @@ __global__ __launch_bounds__(64 * kI8Waves, 1) void gemm_i8h_filter_kernel(
 // HBM-bound by design: 4 MFMAs of 32 cycles per 2 KB of fragments. Each wave is a slice of its own (lists, counts:
 // [nblocks * 8][64]); thresholds, slots, the k rule and the list discipline are gemm_i8h_filter_kernel's. Needs seeded bounds
 // (api.hip picks it only then): an unseeded first tile passes all its sites through the survivors' path, four per round trip.
+// CT = 4 (65 .. 128 queries: four column tiles per wave, 64 accumulator registers): a quarter tile's fragments are requested in two
+// K halves (unit = quarter tile x K half; the accumulators carry over), so that the fragment registers stay at NK x 4.
 constexpr int kI8sBQ = 64, kI8sWaves = 8, kI8sSurvCap = 128;
+template <int CT>
 struct alignas(16) GemmI8sLds {
-    uint32_t cnt[kI8sWaves][kI8sBQ];
-    uint32_t thr[kI8sWaves][kI8sBQ];
+    uint32_t cnt[kI8sWaves][32 * CT];
+    uint32_t thr[kI8sWaves][32 * CT];
     uint32_t surv[kI8sWaves][kI8sSurvCap][4];  // high limb, corpus row, lane | query column tile << 8
 };
-__host__ __device__ inline size_t i8s_dyn_lds_bytes(uint32_t nk) { return (size_t)nk * 4096; }
+__host__ __device__ inline size_t i8s_dyn_lds_bytes(uint32_t nk, uint32_t ct) { return (size_t)nk * 2048 * ct; }
+template <int CT, typename T> __device__ __forceinline__ T i8s_pick(const T (&v)[CT], uint32_t ct) {  // v[ct] without a register-indexed array
+    T r = v[0];
+#pragma unroll
+    for (int x = 1; x < CT; ++x) r = ct == (uint32_t)x ? v[x] : r;
+    return r;
+}
 
-template <int R, int NK>
+template <int R, int NK, int CT>
 __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t nquarter /*quarter tiles: 4 * ntiles*/, uint32_t N,
-    size_t Qpad /*= 64*/, uint32_t quarters_per_wave, const float* __restrict__ qc, uint64_t* __restrict__ lists,
+    size_t Qpad /*= 32 CT*/, uint32_t quarters_per_wave, const float* __restrict__ qc, uint64_t* __restrict__ lists,
     uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr) {
-    extern __shared__ __attribute__((aligned(16))) char i8s_b[];  // [NK][m 2][ct 2][64 lanes] x 16 B: the high limbs as B fragments
-    __shared__ GemmI8sLds s;
+    static_assert(CT == 2 || CT == 4, "two or four column tiles of 32 queries");
+    constexpr int KS = CT == 4 ? 2 : 1, NKH = NK / KS;  // K halves per quarter tile, K-steps per unit
+    static_assert(NK % KS == 0, "the K-step count splits evenly");
+    extern __shared__ __attribute__((aligned(16))) char i8s_b[];  // [NK][m 2][ct CT][64 lanes] x 16 B: the high limbs as B fragments
+    __shared__ GemmI8sLds<CT> s;
     const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);
     constexpr int S = kI8hS;
     constexpr uint32_t cap = 64 * R, nk = NK;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int half = lane >> 5, C = lane & 31;
-    for (uint32_t idx = threadIdx.x; idx < nk * 256; idx += 64 * kI8sWaves) {
-        const uint32_t l = idx & 63, x = idx >> 6, ct = x & 1, m = (x >> 1) & 1, ks = x >> 2;
+    for (uint32_t idx = threadIdx.x; idx < nk * 2 * CT * 64; idx += 64 * kI8sWaves) {
+        const uint32_t l = idx & 63, x = idx >> 6, ct = x % CT, m = (x / CT) & 1, ks = x / (2 * CT);
         reinterpret_cast<uint4*>(i8s_b)[idx] =
             reinterpret_cast<const uint4*>(Bq)[((size_t)(ks * 4 + 2 * m + (l >> 5)) * 2) * Qpad + ct * 32 + (l & 31)];
     }
-    s.cnt[w][lane] = 0;
-    s.thr[w][lane] = 0;
+    for (int x = lane; x < 32 * CT; x += 64) {
+        s.cnt[w][x] = 0;
+        s.thr[w][x] = 0;
+    }
     __syncthreads();  // (the only barrier)
 
     const uint32_t slice = blockIdx.x * kI8sWaves + (uint32_t)wu;
@@ -1262,10 +1276,10 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     if (q1 > nquarter) q1 = nquarter;
     if (q0 > q1) q0 = q1;
     uint64_t* my_lists = lists + (size_t)slice * Qpad * cap;
-    float Aj[2], Bj[2], invAj[2];
-    int32_t lob[2];
+    float Aj[CT], Bj[CT], invAj[CT];
+    int32_t lob[CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
         const size_t q = 32 * ct + C;
         Aj[ct] = qc[q];
         Bj[ct] = qc[Qpad + q];
@@ -1274,48 +1288,64 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     }
     // fragment m of quarter tile q at K-step ks: 16 B of row C of row tile q & 3, k-group 2 m + half
     const i32x4_t* const frag0 = reinterpret_cast<const i32x4_t*>(Ai8) + (size_t)half * 128 + C;
-    auto frag = [&](uint32_t q, int ks, int m) -> i32x4_t {
-        return frag0[(((size_t)(q >> 2) * nk + (uint32_t)ks) * 4 + 2u * (uint32_t)m) * 128 + (q & 3u) * 32u];
+    auto frag = [&](uint32_t q, uint32_t ks, int m) -> i32x4_t {
+        return frag0[(((size_t)(q >> 2) * nk + ks) * 4 + 2u * (uint32_t)m) * 128 + (q & 3u) * 32u];
     };
-    i32x4_t A[NK][2];
-    if (q0 < q1) {
+    const uint32_t u0 = q0 * KS, u1 = q1 * KS;  // units: (quarter tile, K half)
+    i32x4_t A[NKH][2];
+    if (u0 < u1) {
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            A[ks][0] = frag(q0, ks, 0);
-            A[ks][1] = frag(q0, ks, 1);
+        for (int i = 0; i < NKH; ++i) {
+            A[i][0] = frag(q0, (uint32_t)i, 0);
+            A[i][1] = frag(q0, (uint32_t)i, 1);
         }
     }
     uint32_t ns = 0;
-    for (uint32_t q = q0; q < q1; ++q) {
-        // the chip-wide bounds of this quarter tile, requested before its successor's fragments: the oldest request in flight when
-        // the epilogue needs it
-        uint32_t tg_cur[2];
+    uint32_t tg_cur[CT];
+    i32x16_t acc[CT];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) tg_cur[ct] = __hip_atomic_load(gthr + 32 * ct + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t qn = q + 1 < q1 ? q + 1 : q;  // (the last quarter tile requests its own fragments again: no branch in the K loop)
-        i32x16_t acc[1][2];
+    for (int ct = 0; ct < CT; ++ct) {
+        tg_cur[ct] = 0u;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int g = 0; g < 16; ++g) acc[ct][g] = 0;
+    }
+    for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t h = u / KS, kh = u % KS;  // (h: the quarter tile)
+        if (kh == 0) {
+            // the chip-wide bounds of this quarter tile, requested before its successor's fragments: the oldest request in flight
+            // when the epilogue needs it
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[0][ct][g] = 0;
+            for (int ct = 0; ct < CT; ++ct) {
+                tg_cur[ct] = __hip_atomic_load(gthr + 32 * ct + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) {
-            const i32x4_t* bl = reinterpret_cast<const i32x4_t*>(i8s_b) + (size_t)ks * 256 + lane;
-            const i32x4_t b00 = bl[0], b01 = bl[64], b10 = bl[128], b11 = bl[192];  // [m][ct]
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][0], b00, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][0], b01, acc[0][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][1], b10, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks][1], b11, acc[0][1], 0, 0, 0);
-            A[ks][0] = frag(qn, ks, 0);
-            A[ks][1] = frag(qn, ks, 1);
+                for (int g = 0; g < 16; ++g) acc[ct][g] = 0;
+            }
         }
-        const uint32_t h = q;  // (the epilogue's name for the unit it finishes)
-        // ---------------- epilogue of quarter tile h: two queries per lane, 16 corpus rows each ----------------
-        const uint32_t tb = (h >> 2) * 128u, rt0 = h & 3u;
-        uint32_t thr[2];
-        int32_t Tint[2], Thi[2];
+        const uint32_t un = u + 1 < u1 ? u + 1 : u;  // (the last unit requests its own fragments again: no branch in the K loop)
+        const uint32_t qn = un / KS, ksn = (un % KS) * NKH, ks0 = kh * NKH;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int i = 0; i < NKH; ++i) {
+            const i32x4_t* bl = reinterpret_cast<const i32x4_t*>(i8s_b) + (size_t)(ks0 + (uint32_t)i) * (2 * CT * 64) + lane;  // [m][ct][64]
+#pragma unroll
+            for (int cp = 0; cp < CT; cp += 2) {  // two column tiles at a time: four operand registers each
+                const i32x4_t b00 = bl[(0 * CT + cp) * 64], b01 = bl[(0 * CT + cp + 1) * 64];
+                const i32x4_t b10 = bl[(1 * CT + cp) * 64], b11 = bl[(1 * CT + cp + 1) * 64];
+                acc[cp] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i][0], b00, acc[cp], 0, 0, 0);
+                acc[cp + 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i][0], b01, acc[cp + 1], 0, 0, 0);
+                acc[cp] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i][1], b10, acc[cp], 0, 0, 0);
+                acc[cp + 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i][1], b11, acc[cp + 1], 0, 0, 0);
+            }
+            A[i][0] = frag(qn, ksn + (uint32_t)i, 0);
+            A[i][1] = frag(qn, ksn + (uint32_t)i, 1);
+        }
+        if (kh != KS - 1) continue;
+        // ---------------- epilogue of quarter tile h: CT queries per lane, 16 corpus rows each ----------------
+        const uint32_t tb = (h >> 2) * 128u, rt0 = h & 3u;
+        uint32_t thr[CT];
+        int32_t Tint[CT], Thi[CT];
+        bool hit[CT], any = false;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
             const uint32_t tl = __hip_atomic_load(&s.thr[wu][32 * ct + C], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             thr[ct] = tl > tg_cur[ct] ? tl : tg_cur[ct];
             Tint[ct] = INT32_MIN;
@@ -1331,17 +1361,16 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
                     Thi[ct] = d < -2147483000ll ? INT32_MIN : (int32_t)(d >> S);
                 }
             }
-        }
-        bool hit[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
             int32_t m4 = INT32_MIN;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) m4 = m4 > acc[0][ct][g] ? m4 : acc[0][ct][g];
+            for (int g = 0; g < 16; ++g) m4 = m4 > acc[ct][g] ? m4 : acc[ct][g];
             hit[ct] = m4 >= Thi[ct];
+            any = any || hit[ct];
         }
-        if (!__any(hit[0] || hit[1])) continue;
-        bool admitted[2] = {false, false};
+        if (!__any(any)) continue;
+        bool admitted[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) admitted[ct] = false;
         // finish the queued survivors, four per memory round trip (gemm_i8h_filter_kernel's flush: 16 lanes per survivor)
         auto flush = [&]() {
             __builtin_amdgcn_wave_barrier();
@@ -1353,7 +1382,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
                 const uint32_t hi_m = s.surv[wu][em][0], row_m = s.surv[wu][em][1], lc_m = s.surv[wu][em][2];
                 const uint32_t rr = row_m & 127u;
                 const uint4* pa = reinterpret_cast<const uint4*>(Ai8) + ((size_t)(row_m >> 7) * nk * 4) * 128 + (rr & 3u) * 32 + (rr >> 2);
-                const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (32 * ((lc_m >> 8) & 1u) + (lc_m & 31u));
+                const uint4* pb = reinterpret_cast<const uint4*>(Bq) + Qpad + (32 * ((lc_m >> 8) & 3u) + (lc_m & 31u));
                 int32_t part = 0;
                 for (uint32_t c0 = 0; c0 < nk * 4; c0 += 48) {
                     uint4 x[CPL], y[CPL];
@@ -1380,15 +1409,15 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
                     const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)row_m, LPS * (int)g);
                     const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)lc_m, LPS * (int)g);
                     const int L = (int)(lc & 63u);
-                    const bool c1 = ((lc >> 8) & 1u) != 0;
+                    const uint32_t c1 = (lc >> 8) & 3u;  // query column tile (wave-uniform)
                     const int32_t V = (int32_t)(((uint32_t)hiL << S) + (uint32_t)lo);
-                    if (lane == L && V >= (c1 ? Tint[1] : Tint[0])) {
-                        const uint32_t o = f32_ord(__builtin_fmaf(c1 ? Aj[1] : Aj[0], (float)V, c1 ? Bj[1] : Bj[0]));
-                        if (o >= (c1 ? thr[1] : thr[0]) && i < N) {
-                            const int ql = 32 * (c1 ? 1 : 0) + C;
+                    if (lane == L && V >= i8s_pick<CT>(Tint, c1)) {
+                        const uint32_t o = f32_ord(__builtin_fmaf(i8s_pick<CT>(Aj, c1), (float)V, i8s_pick<CT>(Bj, c1)));
+                        if (o >= i8s_pick<CT>(thr, c1) && i < N) {
+                            const int ql = 32 * (int)c1 + C;
                             const bool pub = (i & (kI8hPubEvery - 1)) == 0;
-                            admitted[0] = admitted[0] || (pub && !c1);
-                            admitted[1] = admitted[1] || (pub && c1);
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) admitted[ct] = admitted[ct] || (pub && c1 == (uint32_t)ct);
                             cand_append(my_lists + (size_t)ql * cap, &s.cnt[wu][ql], cap, cand_make(o, i), errflag);
                             gthr_raise(gslots + (size_t)ql * (kSlotMul * KP), kSlotMul * KP, o, i);
                         }
@@ -1399,33 +1428,30 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
             __builtin_amdgcn_wave_barrier();
         };
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             if (!__any(hit[ct])) continue;
 #pragma unroll
-            for (int r2 = 0; r2 < 1; ++r2)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int32_t hi = acc[r2][ct][g];
-                    const bool surv = hit[ct] && hi >= Thi[ct];
-                    const unsigned long long mm = __ballot(surv);
-                    if (!mm) continue;
-                    const uint32_t nm = (uint32_t)__popcll(mm);
-                    if (ns + nm > (uint32_t)kI8sSurvCap) flush();
-                    if (surv) {
-                        const uint32_t slot = ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-                        s.surv[wu][slot][0] = (uint32_t)hi;
-                        s.surv[wu][slot][1] = tb + 4u * ((uint32_t)(g & 3) + 8u * (uint32_t)(g >> 2) + 4u * (uint32_t)half) + rt0 + (uint32_t)r2;
-                        s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
-                    }
-                    ns += nm;
+            for (int g = 0; g < 16; ++g) {
+                const int32_t hi = acc[ct][g];
+                const bool surv = hit[ct] && hi >= Thi[ct];
+                const unsigned long long mm = __ballot(surv);
+                if (!mm) continue;
+                const uint32_t nm = (uint32_t)__popcll(mm);
+                if (ns + nm > (uint32_t)kI8sSurvCap) flush();
+                if (surv) {
+                    const uint32_t slot = ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                    s.surv[wu][slot][0] = (uint32_t)hi;
+                    s.surv[wu][slot][1] = tb + 4u * ((uint32_t)(g & 3) + 8u * (uint32_t)(g >> 2) + 4u * (uint32_t)half) + rt0;
+                    s.surv[wu][slot][2] = (uint32_t)lane | ((uint32_t)ct << 8);
                 }
+                ns += nm;
+            }
         }
         flush();
         // re-derive the chip-wide bounds that asked for it; compact lists that run short of room
-        unsigned long long admitted_by[2] = {__ballot(admitted[0]), __ballot(admitted[1])};
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            unsigned long long m = admitted_by[ct];
+        for (int ct = 0; ct < CT; ++ct) {
+            unsigned long long m = __ballot(admitted[ct]);
             m = (m | (m >> 32)) & 0xffffffffull;
             while (m) {
                 const int L = __builtin_ctzll(m);
@@ -1435,25 +1461,29 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t c = __hip_atomic_load(&s.cnt[wu][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        unsigned long long need = __ballot(c > cap - 32u);  // (a quarter tile appends at most 32 rows to one query's list)
-        while (need) {
-            const int j = __builtin_ctzll(need);
-            need &= need - 1;
-            const uint32_t cj = __builtin_amdgcn_readlane(c, j);
-            uint32_t t;
-            const uint32_t keep = wave_compact<R>(my_lists + (size_t)j * cap, cj, KP, &t);
-            if (lane == 0) {
-                s.cnt[wu][j] = keep;
-                s.thr[wu][j] = t;
-                if (t > __hip_atomic_load(&gthr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    __hip_atomic_fetch_max(&gthr[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int qb = 0; qb < 32 * CT; qb += 64) {
+            const uint32_t c = __hip_atomic_load(&s.cnt[wu][qb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            unsigned long long need = __ballot(c > cap - 32u);  // (a quarter tile appends at most 32 rows to one query's list)
+            while (need) {
+                const int j = __builtin_ctzll(need);
+                need &= need - 1;
+                const uint32_t cj = __builtin_amdgcn_readlane(c, j);
+                uint32_t t;
+                const uint32_t keep = wave_compact<R>(my_lists + (size_t)(qb + j) * cap, cj, KP, &t);
+                if (lane == 0) {
+                    s.cnt[wu][qb + j] = keep;
+                    s.thr[wu][qb + j] = t;
+                    if (t > __hip_atomic_load(&gthr[qb + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        __hip_atomic_fetch_max(&gthr[qb + j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    {
-        const uint32_t c = __hip_atomic_load(&s.cnt[wu][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+    for (int qb = 0; qb < 32 * CT; qb += 64) {
+        const uint32_t c = __hip_atomic_load(&s.cnt[wu][qb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         unsigned long long need = __ballot(c > KP);
         uint32_t mine = c;
         while (need) {
@@ -1461,10 +1491,10 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
             need &= need - 1;
             const uint32_t cj = __builtin_amdgcn_readlane(c, j);
             uint32_t t;
-            const uint32_t keep = wave_compact<R>(my_lists + (size_t)j * cap, cj, KP, &t);
+            const uint32_t keep = wave_compact<R>(my_lists + (size_t)(qb + j) * cap, cj, KP, &t);
             if (lane == j) mine = keep;
         }
-        counts[(size_t)slice * Qpad + lane] = mine;
+        counts[(size_t)slice * Qpad + qb + lane] = mine;
     }
 }
 

@@ -209,9 +209,10 @@ def test_int8_filter_squared_l2(B, innr, n, dim, nq, k):
     _check_knn(B, innr, "dot", vb, oracle.from_rows(rows), qs, min(k, 48), innr.KNN_MFMA_I8)  # (the dot copy beside it, same range)
 
 
-@pytest.mark.parametrize("dim,nq", [(64, 64), (200, 5), (300, 1), (500, 3), (600, 2), (768, 4), (1000, 2)])
+@pytest.mark.parametrize("dim,nq", [(64, 64), (200, 5), (300, 1), (500, 3), (600, 2), (768, 4), (1000, 2),
+                                    (500, 65), (600, 100), (768, 128), (1000, 70)])  # (65 .. 128 queries: four column tiles per wave)
 def test_int8_small_batch_kernel_every_k_step_count(B, innr, dim, nq, ctx_option):
-    """gemm_i8s_filter_kernel (at most 64 queries on a corpus large enough for seeded bounds: every wave streams quarter tiles of its
+    """gemm_i8s_filter_kernel (at most 128 queries on a corpus large enough for seeded bounds: every wave streams quarter tiles of its
     own, the queries' high limbs in LDS): one instantiation per K-step count 2, 4, ... 16 -- dot / cosine / squared L2 (whose copy
     has D + R + 1 dimensions: the next count up for some of these) against the oracle, and against the 512-query-tile kernel
     (option i8_no_small) bit for bit."""

@@ -153,9 +153,9 @@ def test_batch_knn_u8_gemm_engine(S, innr, n, dim, nq, k, alpha, offset, engine_
     assert st.queries_fallback <= max(2, nq // 4), st.queries_fallback
 
 
-@pytest.mark.parametrize("nq,dim", [(1, 128), (9, 96), (64, 200)])
+@pytest.mark.parametrize("nq,dim", [(1, 128), (9, 96), (64, 200), (100, 512), (128, 768)])
 def test_batch_knn_u8_small_batch_kernel(S, innr, nq, dim, ctx_option):
-    """at most 64 queries, lists of 128 (k = 100) and a corpus large enough for seeded bounds: the int8 engine runs
+    """at most 128 queries, lists of 128 (k = 100) and a corpus large enough for seeded bounds: the int8 engine runs
     gemm_i8s_filter_kernel (one wave = one slice, queries in LDS); same answers as the oracle and as the 512-query-tile kernel"""
     n, k, alpha, offset = 140_000, 100, 2.0, -1.0
     codes = _codes(n, dim, 11, alpha, offset)

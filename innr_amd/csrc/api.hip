@@ -2779,7 +2779,12 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     I8Plan p = plan_i8(b, Q, kout);
     const size_t kSeedN = seed_prefix_rows(c, true, Q);
     const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;
-    (void)plan_i8_small(b, &p, Q, seeded);
+    if (!plan_i8_small(b, &p, Q, seeded) && seeded && p.KP < 128 && Q <= 2 * (size_t)kI8sBQ) {
+        // the small-batch kernel is instantiated for lists of 128: a small k takes them too (a capacity, not a threshold -- the k
+        // rule sets the bounds) rather than the 512-query tile
+        I8Plan p2 = plan_i8(b, Q, kout, 128u);
+        if (plan_i8_small(b, &p2, Q, seeded)) p = p2;
+    }
     INNR_TRY(prep_queries_i8(b, p, dQ, Q, qsum, b->alpha, b->offset));
     const float* qc = c->misc.as<float>();
     uint32_t* fallback = reinterpret_cast<uint32_t*>(c->misc.as<char>() + 5 * p.Qpad * sizeof(float));
@@ -3143,10 +3148,15 @@ innr_status innr_batch_knn_u8_dev(innr_batch* b, const float* d_queries, size_t 
     INNR_HIP_CHECK(hipGetLastError());
     if (engine == INNR_KNN_AUTO) {
         engine = innr_batch_auto_engine(b, Q);
-        if (engine == INNR_KNN_MFMA && i8_eligible(b, Q) && !c->tune.u8_no_i8) {
-            // the int8 filter's smallest tile is 512 queries (46 ms at 50M x 768 whatever the batch size); the exact engine's
-            // 8-query passes cost 17.7 ms each there: two passes still win (profiles/r02_u8_exact_scan_50Mx768.txt)
-            engine = Q <= 16 ? INNR_KNN_EXACT : INNR_KNN_MFMA_I8;
+        if (i8_eligible(b, Q) && !c->tune.u8_no_i8 && b->N >= 65536 && gemm_addressable(b, Q)) {
+            // The int8 engine streams its K-packed copy (N*D more bytes of HBM, built on first use) ONCE for up to 128 queries
+            // (gemm_i8s_filter_kernel: 6.0 ms = 6.4 TB/s at 50M x 768 up to 64 queries, 8.1 ms up to 128) where the exact engine takes
+            // 6.4 ms for one query, 8.1 for two, 14.2 for eight (profiles/r03_u8_smallq_50Mx768.txt): from two queries on once the copy
+            // exists, from four when it has to be built and fits with room to spare; larger batches as before.
+            size_t free_b = 0, total_b = 0;
+            const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+            const size_t copy_b = (b->ldN / 128) * (size_t)i8_nk(b) * kI8StageBytes;
+            if (b->Ai8 ? Q >= 2 : (Q >= 4 && have_mem && free_b > 2 * copy_b + ((size_t)8 << 30))) engine = INNR_KNN_MFMA_I8;
         }
     }
     if (engine == INNR_KNN_MFMA_BF16) engine = INNR_KNN_MFMA;  // codes are exact in 8 bits: the low-precision filter is the int8 one

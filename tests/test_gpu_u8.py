@@ -198,8 +198,15 @@ def test_u8_engines_agree_large(S, innr):
         assert st.engine == (innr.KNN_MFMA_I8 if engine == innr.KNN_AUTO else engine)  # AUTO: the int8 filter
         print(f"u8 2Mx128 256q engine {st.engine}: gemm {st.gemm_ms:.2f} ms total {st.total_ms:.2f} ms fallback {st.queries_fallback}")
     st = innr.KnnStats()
-    i1, s1 = qc.knn_multi(qs[:13], 10, engine=innr.KNN_AUTO, stats=st)  # up to 16 queries: two 8-query passes of the exact scan
-    assert st.engine == innr.KNN_EXACT and np.array_equal(i1, i2[:13]) and bits_equal(s1, s2[:13])
+    i1, s1 = qc.knn_multi(qs[:13], 10, engine=innr.KNN_AUTO, stats=st)  # the copy exists: the int8 engine's small-batch kernel
+    assert st.engine == innr.KNN_MFMA_I8 and np.array_equal(i1, i2[:13]) and bits_equal(s1, s2[:13])
+    i1, s1 = qc.knn_multi(qs[:1], 10, engine=innr.KNN_AUTO, stats=st)  # one query: one pass of the exact scan streams the same bytes
+    assert st.engine == innr.KNN_EXACT and np.array_equal(i1, i2[:1]) and bits_equal(s1, s2[:1])
+    qc2 = S.QuantizedCorpus.generate(200_000, 128, p, seed=2)
+    qc2.knn_multi(qs[:3], 10, engine=innr.KNN_AUTO, stats=st)  # no copy yet, three queries: not worth building
+    assert st.engine == innr.KNN_EXACT
+    qc2.knn_multi(qs[:4], 10, engine=innr.KNN_AUTO, stats=st)
+    assert st.engine == innr.KNN_MFMA_I8
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(300_000, 320, 600, 10), (200_000, 1024, 130, 100), (150_000, 256, 1030, 33)])

@@ -1,6 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_u8.py tests/test_gpu_matryoshka.py tests/test_gpu_shards.py -x -q -m gpu > gpurun_out/u8_tests.log 2>&1 || { tail -40 gpurun_out/u8_tests.log; exit 1; }
-tail -2 gpurun_out/u8_tests.log
-timeout -k 10 800 python3 tools/bench_u8_smallq.py 50000000 100 > gpurun_out/r03_u8_smallq_k100_50Mx768.txt 2> gpurun_out/u8_smallq.err
-grep -E "AUTO|#" gpurun_out/r03_u8_smallq_k100_50Mx768.txt
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+for a in "i8 100 dot 8" "i8 100 dot 64" "i8 100 l2 64" "i8 100 dot 128" "i8 100 dot 1" "i8 100 dot 1024" "i8 200 dot 64"; do timeout -k 10 300 python3 tools/run_c2.py $a; done > gpurun_out/i8s_k.log 2>&1
+grep C2 gpurun_out/i8s_k.log

@@ -2638,8 +2638,10 @@ struct I8Plan {
 // The small-batch kernel applies to a one-limb MODE 0 launch of at most 128 queries with lists of 128 whose K-step count has an
 // instantiation (even, <= 16: D <= 1024; the four-column-tile form for 65 .. 128 queries: 8 .. 16) and whose bounds are SEEDED (its
 // survivors' path is built for a trickle, not for the flood of an unseeded first tile).
-static bool plan_i8_small(const innr_batch* b, I8Plan* p, size_t Q, bool seeded) {
-    if (p->two || Q > 2 * (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || p->cap != 768 || !seeded || b->ctx->tune.i8_no_small) return false;
+static bool plan_i8_small(const innr_batch* b, I8Plan* p, size_t Q, bool seeded, bool collect = false) {
+    // (collect mode: fixed thresholds and global lists -- neither the list geometry nor seeding plays a part)
+    if (p->two || Q > 2 * (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || b->ctx->tune.i8_no_small) return false;
+    if (!collect && (p->cap != 768 || !seeded)) return false;
     if (Q > (size_t)kI8sBQ && (p->nk < 8 || b->ctx->tune.i8_no_small4)) return false;
     const uint32_t nquarter = 4 * p->ntiles;
     p->small = true;
@@ -2697,17 +2699,17 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
         else gemm_i8h_filter_kernel<RR, MODE><<<p.nblocks, 64 * kI8Waves, 0, c->stream>>>(INNR_I8_ARGS);                     \
     } while (0)
     if (p.small) {
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 0 || MODE == 2) {
             const size_t dyn = i8s_dyn_lds_bytes(p.nk, p.small_ct);
 #define INNR_I8S_LAUNCH(NKV, CTV)                                                                                                    \
     do {                                                                                                                            \
         static bool raised = false;  /* (per instantiation) */                                                                      \
         if (dyn > 48 * 1024 && !raised) {                                                                                           \
-            INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV, CTV>),                 \
+            INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV, CTV, MODE>),           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8s_dyn_lds_bytes(NKV, CTV)));      \
             raised = true;                                                                                                          \
         }                                                                                                                           \
-        gemm_i8s_filter_kernel<12, NKV, CTV><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                         \
+        gemm_i8s_filter_kernel<12, NKV, CTV, MODE><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                   \
             corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.tps, qc, c->lists.as<uint64_t>(),                 \
             c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot);                                   \
     } while (0)
@@ -2983,7 +2985,7 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     if (l2) p.nk = b->ai8l_nk;
     const size_t kSeedN = seed_prefix_rows(c, true, Q);
     const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;
-    if (!collect_kth) (void)plan_i8_small(b, &p, Q, seeded);
+    (void)plan_i8_small(b, &p, Q, seeded, collect_kth != nullptr);
     // exact query norms; cosine: 1/||q|| and the normalised copy the filter multiplies; sum and L1 norm of what it multiplies
     INNR_TRY(c->q_norm.ensure(p.Qpad * sizeof(float)));
     INNR_TRY(c->tmp_norms.ensure(6 * p.Qpad * sizeof(float)));
@@ -3111,7 +3113,8 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     //  whose error is relative, on this corpus from now on -- and looks at the int8 one again every 64th call, innr_batch_knn_dev)
     if (direct && Q >= 16) (cos ? b->i8n_weak : (l2 ? b->i8l_weak : b->i8_weak)) = redo.size() * 2 > Q;
     // ONE more pass of this filter in collect mode settles the unproven queries (k beyond the direct lists: nearly all of them)
-    if (redo.size() > 8 && !c->tune.no_completion) {
+    // (from the first unproven query on: one more pass over the int8 copy costs less than an exact pass over the f32 corpus)
+    if (!redo.empty() && !c->tune.no_completion) {
         std::vector<uint32_t> still;
         INNR_TRY(knn_complete_i8(b, metric, dQ, redo, kout, d_out_idx, d_out_score, &still, gemm_ms));
         redo.swap(still);

@@ -1244,12 +1244,15 @@ template <int CT, typename T> __device__ __forceinline__ T i8s_pick(const T (&v)
     return r;
 }
 
-template <int R, int NK, int CT>
+// MODE 0: fused top-k filter; MODE 2: collect (fixed thresholds in gthr, global uint32 lists [Qpad][KP], lengths in counts) -- as in
+// gemm_i8h_filter_kernel.
+template <int R, int NK, int CT, int MODE>
 __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t nquarter /*quarter tiles: 4 * ntiles*/, uint32_t N,
     size_t Qpad /*= 32 CT*/, uint32_t quarters_per_wave, const float* __restrict__ qc, uint64_t* __restrict__ lists,
     uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr) {
     static_assert(CT == 2 || CT == 4, "two or four column tiles of 32 queries");
+    static_assert(MODE == 0 || MODE == 2, "filter or collect");
     constexpr int KS = CT == 4 ? 2 : 1, NKH = NK / KS;  // K halves per quarter tile, K-steps per unit
     static_assert(NK % KS == 0, "the K-step count splits evenly");
     extern __shared__ __attribute__((aligned(16))) char i8s_b[];  // [NK][m 2][ct CT][64 lanes] x 16 B: the high limbs as B fragments
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
         bool hit[CT], any = false;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const uint32_t tl = __hip_atomic_load(&s.thr[wu][32 * ct + C], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t tl = MODE == 2 ? 0u : __hip_atomic_load(&s.thr[wu][32 * ct + C], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             thr[ct] = tl > tg_cur[ct] ? tl : tg_cur[ct];
             Tint[ct] = INT32_MIN;
             Thi[ct] = INT32_MIN;
@@ -1415,11 +1418,16 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
                         const uint32_t o = f32_ord(__builtin_fmaf(i8s_pick<CT>(Aj, c1), (float)V, i8s_pick<CT>(Bj, c1)));
                         if (o >= i8s_pick<CT>(thr, c1) && i < N) {
                             const int ql = 32 * (int)c1 + C;
-                            const bool pub = (i & (kI8hPubEvery - 1)) == 0;
+                            if (MODE == 2) {  // collect: the query's global list
+                                const uint32_t pos = atomicAdd(counts + ql, 1u);
+                                if (pos < KP) reinterpret_cast<uint32_t*>(lists)[(size_t)ql * KP + pos] = i;
+                            } else {
+                                const bool pub = (i & (kI8hPubEvery - 1)) == 0;
 #pragma unroll
-                            for (int ct = 0; ct < CT; ++ct) admitted[ct] = admitted[ct] || (pub && c1 == (uint32_t)ct);
-                            cand_append(my_lists + (size_t)ql * cap, &s.cnt[wu][ql], cap, cand_make(o, i), errflag);
-                            gthr_raise(gslots + (size_t)ql * (kSlotMul * KP), kSlotMul * KP, o, i);
+                                for (int ct = 0; ct < CT; ++ct) admitted[ct] = admitted[ct] || (pub && c1 == (uint32_t)ct);
+                                cand_append(my_lists + (size_t)ql * cap, &s.cnt[wu][ql], cap, cand_make(o, i), errflag);
+                                gthr_raise(gslots + (size_t)ql * (kSlotMul * KP), kSlotMul * KP, o, i);
+                            }
                         }
                     }
                 }
@@ -1448,6 +1456,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
             }
         }
         flush();
+        if (MODE == 2) continue;  // collect: no bound moves, no list to compact
         // re-derive the chip-wide bounds that asked for it; compact lists that run short of room
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -1481,6 +1490,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (MODE == 2) return;
 #pragma unroll
     for (int qb = 0; qb < 32 * CT; qb += 64) {
         const uint32_t c = __hip_atomic_load(&s.cnt[wu][qb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

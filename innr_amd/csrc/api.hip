@@ -93,6 +93,7 @@ struct innr_tuning {
     long i8_slices_per_cu = 0;   // corpus slices (= blocks) per CU and query tile of the int8 filters; 0 = by metric (plan_i8)
     long i8_no_small = 0;        // never the small-batch int8 kernel (gemm_i8s_filter_kernel): A/B against the 512-query tile
     long i8_no_small4 = 0;       // ... never its four-column-tile form (65 .. 128 queries)
+    long i8_small_max_q = 0;     // ... its largest batch (groups of 128 queries beyond 128); 0 = the default
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -104,7 +105,7 @@ static const TuneName kTuneNames[] = {
     {"maxsim_generic", &innr_tuning::maxsim_generic}, {"no_k_rule", &innr_tuning::no_k_rule},
     {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
     {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu}, {"i8_no_small", &innr_tuning::i8_no_small},
-    {"i8_no_small4", &innr_tuning::i8_no_small4},
+    {"i8_no_small4", &innr_tuning::i8_no_small4}, {"i8_small_max_q", &innr_tuning::i8_small_max_q},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -2640,16 +2641,26 @@ struct I8Plan {
 // survivors' path is built for a trickle, not for the flood of an unseeded first tile).
 static bool plan_i8_small(const innr_batch* b, I8Plan* p, size_t Q, bool seeded, bool collect = false) {
     // (collect mode: fixed thresholds and global lists -- neither the list geometry nor seeding plays a part)
-    if (p->two || Q > 2 * (size_t)kI8sBQ || p->nk > 16 || (p->nk & 1) || b->ctx->tune.i8_no_small) return false;
+    if (p->two || p->nk > 16 || (p->nk & 1) || b->ctx->tune.i8_no_small) return false;
     if (!collect && (p->cap != 768 || !seeded)) return false;
-    if (Q > (size_t)kI8sBQ && (p->nk < 8 || b->ctx->tune.i8_no_small4)) return false;
+    // beyond 64 queries: groups of 128 (four column tiles per wave), each a block of its own per corpus slice, the groups of a slice
+    // side by side on one XCD (the slice comes from HBM once, the other groups read it from that XCD's L2)
+    // (measured at C2, kernel ms, groups against the 512-query tile: 256 queries 2.63 / 3.55, 384: 3.77 / ~3.8, 512: 4.92 / 4.12, 1024:
+    //  9.50 / 8.06 -- every group past the first costs another 1.15 ms = the copy at the streaming rate again: the groups of a slice
+    //  drift apart and the XCD's L2 does not hold them together; profiles/r03_i8s_groups_c2.txt)
+    const long maxq = b->ctx->tune.i8_small_max_q > 0 ? b->ctx->tune.i8_small_max_q : 256;
+    if (Q > (size_t)kI8sBQ && (p->nk < 8 || b->ctx->tune.i8_no_small4 || Q > (size_t)std::min<long>(maxq, 1024))) return false;
     const uint32_t nquarter = 4 * p->ntiles;
     p->small = true;
     p->small_ct = Q > (size_t)kI8sBQ ? 4u : 2u;
-    p->Qpad = 32 * p->small_ct;
-    p->nqt = p->qtg = 1;
-    p->nblocks = std::max(1u, std::min((uint32_t)b->ctx->num_cus, (nquarter + kI8sWaves - 1) / kI8sWaves));
-    p->nslices = p->nblocks * kI8sWaves;
+    const uint32_t per = 32 * p->small_ct;
+    p->nqt = p->qtg = (uint32_t)((Q + per - 1) / per);
+    p->Qpad = (size_t)per * p->nqt;
+    // blocks: nqt groups x slices; slices a multiple of 8 (XCDs), at most one block per CU
+    uint32_t slices = std::max(1u, (uint32_t)b->ctx->num_cus / (8 * p->nqt)) * 8;
+    slices = std::min(slices, std::max(8u, (nquarter + kI8sWaves - 1) / kI8sWaves / 8 * 8));
+    p->nblocks = slices * p->nqt;
+    p->nslices = slices * kI8sWaves;
     p->tps = (nquarter + p->nslices - 1) / p->nslices;
     return true;
 }
@@ -2710,7 +2721,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
             raised = true;                                                                                                          \
         }                                                                                                                           \
         gemm_i8s_filter_kernel<12, NKV, CTV, MODE><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                   \
-            corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.tps, qc, c->lists.as<uint64_t>(),                 \
+            corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.nqt, p.tps, qc, c->lists.as<uint64_t>(),          \
             c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot);                                   \
     } while (0)
             if (p.small_ct == 4) {
@@ -2781,7 +2792,7 @@ static innr_status knn_u8_i8(innr_batch* b, const float* dQ, size_t Q, size_t ko
     I8Plan p = plan_i8(b, Q, kout);
     const size_t kSeedN = seed_prefix_rows(c, true, Q);
     const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;
-    if (!plan_i8_small(b, &p, Q, seeded) && seeded && p.KP < 128 && Q <= 2 * (size_t)kI8sBQ) {
+    if (!plan_i8_small(b, &p, Q, seeded) && seeded && p.KP < 128 && Q <= 1024) {
         // the small-batch kernel is instantiated for lists of 128: a small k takes them too (a capacity, not a threshold -- the k
         // rule sets the bounds) rather than the 512-query tile
         I8Plan p2 = plan_i8(b, Q, kout, 128u);

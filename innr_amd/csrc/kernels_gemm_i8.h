@@ -1249,20 +1249,31 @@ template <int CT, typename T> __device__ __forceinline__ T i8s_pick(const T (&v)
 template <int R, int NK, int CT, int MODE>
 __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t nquarter /*quarter tiles: 4 * ntiles*/, uint32_t N,
-    size_t Qpad /*= 32 CT*/, uint32_t quarters_per_wave, const float* __restrict__ qc, uint64_t* __restrict__ lists,
-    uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag, uint32_t* gslots, uint32_t* gthr) {
+    size_t Qpad /*= 32 CT nqt*/, uint32_t nqt /*query groups of 32 CT*/, uint32_t quarters_per_wave, const float* __restrict__ qc,
+    uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag,
+    uint32_t* gslots, uint32_t* gthr) {
     static_assert(CT == 2 || CT == 4, "two or four column tiles of 32 queries");
     static_assert(MODE == 0 || MODE == 2, "filter or collect");
     constexpr int KS = CT == 4 ? 2 : 1, NKH = NK / KS;  // K halves per quarter tile, K-steps per unit
     static_assert(NK % KS == 0, "the K-step count splits evenly");
     extern __shared__ __attribute__((aligned(16))) char i8s_b[];  // [NK][m 2][ct CT][64 lanes] x 16 B: the high limbs as B fragments
     __shared__ GemmI8sLds<CT> s;
-    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad);
     constexpr int S = kI8hS;
     constexpr uint32_t cap = 64 * R, nk = NK;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int half = lane >> 5, C = lane & 31;
+    // Several query groups (nqt > 1: more than 32 CT queries): the blocks of ONE corpus slice -- one per group -- sit on the same XCD
+    // (block b runs on XCD b % 8) next to each other in launch order, so that the slice is fetched from HBM once and served to the
+    // other groups by that XCD's L2.
+    const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, grp = lb % nqt, slice_blk = xcd * (gridDim.x / (8u * nqt)) + lb / nqt;
+    const size_t q0 = (size_t)grp * (32 * CT);
+    Bq += q0 * 16;          // (every [..][Qpad][16 B] plane of the packed queries)
+    qc += q0;
+    gslots += q0 * (size_t)(kSlotMul * KP);
+    counts += q0;
+    const float* const kmargin = reinterpret_cast<const float*>(gthr + Qpad) + q0;  // (behind the bounds of ALL groups)
+    gthr += q0;
     for (uint32_t idx = threadIdx.x; idx < nk * 2 * CT * 64; idx += 64 * kI8sWaves) {
         const uint32_t l = idx & 63, x = idx >> 6, ct = x % CT, m = (x / CT) & 1, ks = x / (2 * CT);
         reinterpret_cast<uint4*>(i8s_b)[idx] =
@@ -1274,11 +1285,11 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     }
     __syncthreads();  // (the only barrier)
 
-    const uint32_t slice = blockIdx.x * kI8sWaves + (uint32_t)wu;
-    uint32_t q0 = slice * quarters_per_wave, q1 = q0 + quarters_per_wave;
-    if (q1 > nquarter) q1 = nquarter;
-    if (q0 > q1) q0 = q1;
-    uint64_t* my_lists = lists + (size_t)slice * Qpad * cap;
+    const uint32_t slice = slice_blk * kI8sWaves + (uint32_t)wu;
+    uint32_t qt0 = slice * quarters_per_wave, qt1 = qt0 + quarters_per_wave;
+    if (qt1 > nquarter) qt1 = nquarter;
+    if (qt0 > qt1) qt0 = qt1;
+    uint64_t* my_lists = lists + ((size_t)slice * Qpad + q0) * cap;
     float Aj[CT], Bj[CT], invAj[CT];
     int32_t lob[CT];
 #pragma unroll
@@ -1294,13 +1305,13 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     auto frag = [&](uint32_t q, uint32_t ks, int m) -> i32x4_t {
         return frag0[(((size_t)(q >> 2) * nk + ks) * 4 + 2u * (uint32_t)m) * 128 + (q & 3u) * 32u];
     };
-    const uint32_t u0 = q0 * KS, u1 = q1 * KS;  // units: (quarter tile, K half)
+    const uint32_t u0 = qt0 * KS, u1 = qt1 * KS;  // units: (quarter tile, K half)
     i32x4_t A[NKH][2];
     if (u0 < u1) {
 #pragma unroll
         for (int i = 0; i < NKH; ++i) {
-            A[i][0] = frag(q0, (uint32_t)i, 0);
-            A[i][1] = frag(q0, (uint32_t)i, 1);
+            A[i][0] = frag(qt0, (uint32_t)i, 0);
+            A[i][1] = frag(qt0, (uint32_t)i, 1);
         }
     }
     uint32_t ns = 0;
@@ -1420,7 +1431,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
                             const int ql = 32 * (int)c1 + C;
                             if (MODE == 2) {  // collect: the query's global list
                                 const uint32_t pos = atomicAdd(counts + ql, 1u);
-                                if (pos < KP) reinterpret_cast<uint32_t*>(lists)[(size_t)ql * KP + pos] = i;
+                                if (pos < KP) reinterpret_cast<uint32_t*>(lists)[(q0 + (size_t)ql) * KP + pos] = i;
                             } else {
                                 const bool pub = (i & (kI8hPubEvery - 1)) == 0;
 #pragma unroll

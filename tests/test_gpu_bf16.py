@@ -210,7 +210,8 @@ def test_int8_filter_squared_l2(B, innr, n, dim, nq, k):
 
 
 @pytest.mark.parametrize("dim,nq", [(64, 64), (200, 5), (300, 1), (500, 3), (600, 2), (768, 4), (1000, 2),
-                                    (500, 65), (600, 100), (768, 128), (1000, 70)])  # (65 .. 128 queries: four column tiles per wave)
+                                    (500, 65), (600, 100), (768, 128), (1000, 70),  # (65 .. 128 queries: four column tiles per wave)
+                                    (600, 200), (768, 256)])  # (two query groups: a block per group and corpus slice)
 def test_int8_small_batch_kernel_every_k_step_count(B, innr, dim, nq, ctx_option):
     """gemm_i8s_filter_kernel (at most 128 queries on a corpus large enough for seeded bounds: every wave streams quarter tiles of its
     own, the queries' high limbs in LDS): one instantiation per K-step count 2, 4, ... 16 -- dot / cosine / squared L2 (whose copy

@@ -106,7 +106,7 @@ innr_status innr_ctx_synchronize(innr_ctx* ctx);
 /* Tuning / experiment switches of a context (no reference counterpart: innr has no configuration). Their defaults are read from
  * the environment ONCE, in innr_ctx_create (INNR_<NAME IN CAPITALS>); no call reads the environment afterwards. Names:
  * gemm_waves, gemm_blocks_per_cu, gemm_qt_group, gemm_seed_n, gemm_no_seed, gemm_no_kp_retry, i8_two_limb, no_auto_bf16,
- * no_auto_i8, u8_no_i8, rescore_all, maxsim_generic, no_k_rule, no_completion, no_rows_copy, i8_slices_per_cu, i8_no_small, i8_no_small4, i8_small_max_q, trace, fail_local_search (a test
+ * no_auto_i8, u8_no_i8, rescore_all, maxsim_generic, no_k_rule, no_completion, no_rows_copy, i8_slices_per_cu, i8_no_small, i8_no_small4, i8_small_max_q, i8_small_free, trace, fail_local_search (a test
  * switch of the sharded calls) -- DESIGN.md lists what each one does. None of them changes a result. Unknown name: INNR_E_BAD_ARG. */
 innr_status innr_ctx_set_option(innr_ctx* ctx, const char* name, long value);
 innr_status innr_ctx_get_option(innr_ctx* ctx, const char* name, long* value);

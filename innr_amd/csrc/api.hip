@@ -94,6 +94,7 @@ struct innr_tuning {
     long i8_no_small = 0;        // never the small-batch int8 kernel (gemm_i8s_filter_kernel): A/B against the 512-query tile
     long i8_no_small4 = 0;       // ... never its four-column-tile form (65 .. 128 queries)
     long i8_small_max_q = 0;     // ... its largest batch (groups of 128 queries beyond 128); 0 = the default
+    long i8_small_free = 0;      // ... its query groups run free (no soft lockstep): A/B
 };
 struct TuneName { const char* name; long innr_tuning::*field; };
 static const TuneName kTuneNames[] = {
@@ -106,6 +107,7 @@ static const TuneName kTuneNames[] = {
     {"fail_local_search", &innr_tuning::fail_local_search}, {"no_completion", &innr_tuning::no_completion}, {"trace", &innr_tuning::trace}, {"no_rows_copy", &innr_tuning::no_rows_copy},
     {"i8_slices_per_cu", &innr_tuning::i8_slices_per_cu}, {"i8_no_small", &innr_tuning::i8_no_small},
     {"i8_no_small4", &innr_tuning::i8_no_small4}, {"i8_small_max_q", &innr_tuning::i8_small_max_q},
+    {"i8_small_free", &innr_tuning::i8_small_free},
 };
 static void tuning_from_env(innr_tuning* t) {
     for (const TuneName& n : kTuneNames) {
@@ -151,6 +153,7 @@ struct innr_ctx {
     DevBuf sel_cnt;   // [Q]
     DevBuf gthr;           // GEMM engine: global threshold slots + bounds + k-rule margins
     DevBuf kmargin;        // [Qpad] 2E per query, staged for prep_gthr
+    DevBuf i8s_prog;       // gemm_i8s_filter_kernel with several query groups: [wave slices][groups] positions (soft lockstep)
     DevBuf sel_tmp[2];     // multi-level select: [parts][Q][KP]
     DevBuf selcnt_tmp[2];  // [parts][Q]
     DevBuf scores;    // [QB][ldN] materialised scores
@@ -1470,7 +1473,7 @@ void innr_ctx_destroy(innr_ctx* c) {
                       &c->q_row, &c->q_kmajor, &c->q_norm, &c->lists, &c->counts, &c->sel, &c->sel_cnt,
                       &c->scores, &c->tmp_norms, &c->flags, &c->out_idx, &c->out_score, &c->misc, &c->seed_idx, &c->seed_score, &c->q_one, &c->sort_keys, &c->sort_tmp, &c->q_bf16, &c->q_pad, &c->q_hat,
                       &c->redo[0].q, &c->redo[0].idx, &c->redo[0].sc, &c->redo[0].map, &c->redo[0].qn,
-                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn, &c->kmargin,
+                      &c->redo[1].q, &c->redo[1].idx, &c->redo[1].sc, &c->redo[1].map, &c->redo[1].qn, &c->kmargin, &c->i8s_prog,
                       &c->cmpl.q, &c->cmpl.idx, &c->cmpl.sc, &c->cmpl.map, &c->cmpl.qn};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
@@ -2712,6 +2715,12 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
     if (p.small) {
         if constexpr (MODE == 0 || MODE == 2) {
             const size_t dyn = i8s_dyn_lds_bytes(p.nk, p.small_ct);
+            uint32_t* prog = nullptr;
+            if (p.nqt > 1 && !c->tune.i8_small_free) {
+                INNR_TRY(c->i8s_prog.ensure((size_t)p.nslices * p.nqt * sizeof(uint32_t)));
+                INNR_HIP_CHECK(hipMemsetAsync(c->i8s_prog.p, 0, (size_t)p.nslices * p.nqt * sizeof(uint32_t), c->stream));
+                prog = c->i8s_prog.as<uint32_t>();
+            }
 #define INNR_I8S_LAUNCH(NKV, CTV)                                                                                                    \
     do {                                                                                                                            \
         static bool raised = false;  /* (per instantiation) */                                                                      \
@@ -2722,7 +2731,7 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
         }                                                                                                                           \
         gemm_i8s_filter_kernel<12, NKV, CTV, MODE><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                   \
             corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.nqt, p.tps, qc, c->lists.as<uint64_t>(),          \
-            c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot);                                   \
+            c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot, prog);                             \
     } while (0)
             if (p.small_ct == 4) {
                 switch (p.nk) {  // (plan_i8_small: even, 8 .. 16)

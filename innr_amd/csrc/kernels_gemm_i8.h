@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
     const char* __restrict__ Ai8, const char* __restrict__ Bq, uint32_t nquarter /*quarter tiles: 4 * ntiles*/, uint32_t N,
     size_t Qpad /*= 32 CT nqt*/, uint32_t nqt /*query groups of 32 CT*/, uint32_t quarters_per_wave, const float* __restrict__ qc,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t KP, uint32_t kk, uint32_t* __restrict__ errflag,
-    uint32_t* gslots, uint32_t* gthr) {
+    uint32_t* gslots, uint32_t* gthr, uint32_t* progress /*[wave slices][nqt], zeroed; null: the groups run free*/) {
     static_assert(CT == 2 || CT == 4, "two or four column tiles of 32 queries");
     static_assert(MODE == 0 || MODE == 2, "filter or collect");
     constexpr int KS = CT == 4 ? 2 : 1, NKH = NK / KS;  // K halves per quarter tile, K-steps per unit
@@ -1323,8 +1323,39 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[ct][g] = 0;
     }
+    // Soft lockstep of the groups (nqt > 1): wave w of every group walks the SAME quarter tiles; if they pass a tile within a few tiles
+    // of each other the first one fetches it from HBM and the others read it from the XCD's L2 (4 MB: 4 slices x 8 waves x the
+    // window). Left alone they drift -- unequal groups at once (200 queries: 3.4 ms against 2.6 for 256), equal ones beyond two
+    // groups (every further group cost the copy at the streaming rate again). Every kI8sSyncEvery quarter tiles a wave publishes its
+    // position and waits until no group is more than kI8sSyncWindow tiles behind: a BOUNDED number of polls -- a group that never
+    // shows up (its block not resident) switches the waiting off for good instead of hanging the launch.
+    constexpr uint32_t kI8sSyncEvery = 2, kI8sSyncWindow = 4, kI8sSyncPolls = 4096;
+    uint32_t* const prog = progress ? progress + (size_t)slice * nqt : nullptr;
+    bool sync_on = prog != nullptr && nqt > 1;
     for (uint32_t u = u0; u < u1; ++u) {
         const uint32_t h = u / KS, kh = u % KS;  // (h: the quarter tile)
+        if (kh == 0 && sync_on && ((h - qt0) % kI8sSyncEvery) == 0) {
+            const uint32_t r = h - qt0;
+            if (lane == 0) __hip_atomic_store(prog + grp, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r > kI8sSyncWindow) {
+                uint32_t polls = 0;
+                while (true) {
+                    const uint32_t v = (uint32_t)lane < nqt ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+                    uint32_t mn = v;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const uint32_t o = (uint32_t)__shfl_xor((int)mn, off, 64);
+                        mn = o < mn ? o : mn;
+                    }
+                    if (mn + kI8sSyncWindow >= r) break;
+                    if (++polls >= kI8sSyncPolls) {
+                        sync_on = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+        }
         if (kh == 0) {
             // the chip-wide bounds of this quarter tile, requested before its successor's fragments: the oldest request in flight
             // when the epilogue needs it
@@ -1501,6 +1532,7 @@ __global__ __launch_bounds__(64 * kI8sWaves, 1) void gemm_i8s_filter_kernel(
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (prog && nqt > 1 && lane == 0) __hip_atomic_store(prog + grp, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (done: nobody waits for this wave)
     if (MODE == 2) return;
 #pragma unroll
     for (int qb = 0; qb < 32 * CT; qb += 64) {

@@ -488,14 +488,15 @@ __global__ __launch_bounds__(64) void rescore_kernel(const float* __restrict__ V
         const uint32_t i = cand_idx(sel[(size_t)q * KP + c]);
         const float* col = V + i;
         float acc = 0.0f;
+        // (32 column loads in flight per lane: the sum is sequential, its operands are not -- at 8 a one-query call spent 0.10 ms here)
         if (L2) {
-#pragma unroll 8
+#pragma unroll 32
             for (uint32_t d = 0; d < D; ++d) {
                 const float diff = ex::sub_keepnan(qv[d], col[(size_t)d * ldN]);
                 acc = ex::mad2(acc, diff, diff);
             }
         } else {
-#pragma unroll 8
+#pragma unroll 32
             for (uint32_t d = 0; d < D; ++d) acc = ex::mad2(acc, qv[d], col[(size_t)d * ldN]);
         }
         if (COS) {

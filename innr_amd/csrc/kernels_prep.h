@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void query_norms_kernel(const float* __restrict
         const float x = d < D ? row[d] : 0.0f;
         const float p = ex::mul(x, x);
         const uint32_t n = D - d0 < 64u ? D - d0 : 64u;
-        for (uint32_t l = 0; l < n; ++l) s = ex::add(s, __shfl(p, (int)l, 64));
+        for (uint32_t l = 0; l < n; ++l) s = ex::add(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), (int)l)));  // (l is wave-uniform)
     }
     if (lane == 0) qnorm[j] = ex::sqrt(s);
 }

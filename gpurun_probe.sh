@@ -1,7 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
-tail -2 gpurun_out/gpu_tests.log
-timeout -k 10 400 python3 tools/bench_u8.py > gpurun_out/r03_c3_i8.json 2> gpurun_out/c3.err
-python3 -c "
-import json; d=json.load(open('gpurun_out/r03_c3_i8.json')); print('C3', d['total_ms'], d['gemm_ms'])"
+timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_u8.py tests/test_gpu_mfma.py -x -q -m gpu > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
+tail -1 gpurun_out/t.log
+bash tools/profile_round.sh r03 > gpurun_out/profile_round.log 2>&1 || { tail -30 gpurun_out/profile_round.log; exit 1; }
+tail -1 gpurun_out/profile_round.log | cut -c1-300

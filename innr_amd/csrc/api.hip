@@ -2723,12 +2723,9 @@ static innr_status launch_gemm_i8(innr_batch* b, const I8Plan& p, size_t nreal_q
             }
 #define INNR_I8S_LAUNCH(NKV, CTV)                                                                                                    \
     do {                                                                                                                            \
-        static bool raised = false;  /* (per instantiation) */                                                                      \
-        if (dyn > 48 * 1024 && !raised) {                                                                                           \
+        if (dyn > 48 * 1024) /* (per device and call: no process-wide state) */                                                      \
             INNR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_i8s_filter_kernel<12, NKV, CTV, MODE>),           \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8s_dyn_lds_bytes(NKV, CTV)));      \
-            raised = true;                                                                                                          \
-        }                                                                                                                           \
         gemm_i8s_filter_kernel<12, NKV, CTV, MODE><<<p.nblocks, 64 * kI8sWaves, dyn, c->stream>>>(                                   \
             corpus, c->q_bf16.as<char>(), 4 * p.ntiles, (uint32_t)b->N, p.Qpad, p.nqt, p.tps, qc, c->lists.as<uint64_t>(),          \
             c->counts.as<uint32_t>(), p.KP, kk, c->flags.as<uint32_t>(), gslots, gslots + nslot, prog);                             \

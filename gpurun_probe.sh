@@ -1,6 +1,6 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_u8.py tests/test_gpu_mfma.py -x -q -m gpu > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
-tail -1 gpurun_out/t.log
-bash tools/profile_round.sh r03 > gpurun_out/profile_round.log 2>&1 || { tail -30 gpurun_out/profile_round.log; exit 1; }
-tail -1 gpurun_out/profile_round.log | cut -c1-300
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+for a in "i8 32 dot 8" "i8 48 dot 64" "i8 48 dot 1024" "i8 32 l2 1024" "i8 20 cos 1024" "i8 100 dot 1024"; do timeout -k 10 300 python3 tools/run_c2.py $a; done > gpurun_out/i8s_k.log 2>&1
+grep C2 gpurun_out/i8s_k.log

@@ -2997,8 +2997,12 @@ innr_status innr::knn_f32_i8(innr_batch* b, int metric, const float* dQ, size_t 
     // Lists of 4k + 64 let the k-th exact score clear the KP-th approximate one by a visible margin (k <= 48); beyond that the
     // lists hold k + 16 (one-limb kernel up to 128, two-limb kernel to 256), most proofs fail BY DESIGN and the completion pass
     // (one more pass of this filter in collect mode) settles them: k = 100 at C2 needs ~450 candidates per query.
-    const bool direct = pick_kp(4 * kout + 64, 0) <= 256;
-    I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? pick_kp(4 * kout + 64, 0) : pick_kp(kout, 16)), collect_kth != nullptr);
+    // k = 17 .. 48: direct lists would be 256 long -- the two-limb kernel (21.7 ms at C2 for k = 48, 4.7 ms for eight queries). With
+    // the k rule setting the bounds, lists of 128 prove most of those answers as well (k = 32: all of a batch of eight; k = 48: 59 of
+    // 64) and the collect pass settles the rest: 2.1 ms for eight queries at k = 32, 4.0 for 64 at k = 48.
+    const uint32_t direct_kp = pick_kp(4 * kout + 64, 0);
+    const bool direct = direct_kp <= 128;
+    I8Plan p = plan_i8(b, Q, kout, collect_kth ? 32u : (direct ? direct_kp : std::max(128u, pick_kp(kout, 16))), collect_kth != nullptr);
     if (l2) p.nk = b->ai8l_nk;
     const size_t kSeedN = seed_prefix_rows(c, true, Q);
     const bool seeded = b->N >= 32 * kSeedN && p.KP <= 128 && !c->tune.gemm_no_seed;

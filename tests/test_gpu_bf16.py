@@ -232,3 +232,16 @@ def test_int8_small_batch_kernel_every_k_step_count(B, innr, dim, nq, ctx_option
         i2, s2 = fn(qs, vb, 10, engine=innr.KNN_MFMA_I8)
         ctx_option("i8_no_small", 0)
         assert np.array_equal(i1, i2) and bits_equal(s1, s2)
+
+
+@pytest.mark.parametrize("k,nq", [(20, 9), (48, 70), (33, 1)])
+def test_int8_small_batch_k_17_to_48(B, innr, k, nq):
+    """k = 17 .. 48 in a small batch: lists of 128 on the small-batch kernel plus its collect pass for the proofs that fail (direct
+    lists would be 256 long: the two-limb kernel). Same answers as the oracle."""
+    n, dim = 140_000, 128
+    rows, _ = _corpus(n, dim, 8, uniform=True)
+    data = oracle.from_rows(rows)
+    qs = _queries(nq, dim, 17, uniform=True)
+    vb = None
+    for metric in ("dot", "cos", "l2"):
+        vb = _check_knn(B, innr, metric, vb if vb is not None else rows, data, qs, k, innr.KNN_MFMA_I8)

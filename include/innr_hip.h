@@ -68,8 +68,9 @@ typedef int innr_status;
                             * HBM), the f32 query as a 14-bit fixed-point value -- its high int8 limb on the matrix pipe, the low
                             * limb bounded in the filter and computed exactly for the survivors (lists of 256: a 16-bit value, both
                             * limbs on the pipe). Needs alpha > 0 and D <= 65535; otherwise INNR_KNN_MFMA serves the call.
-                            * INNR_KNN_AUTO picks it on large code corpora from two queries on once the copy exists (from four when it
-                            * has to be built and fits): up to 128 queries cost one pass over the copy.
+                            * INNR_KNN_AUTO picks it on large code corpora from two queries on once the copy exists (from four -- or
+                            * with the fourth smaller call -- when it has to be built and fits): up to 128 queries cost one pass
+                            * over the copy.
                             * innr_batch_knn[_dev] on an F32 batch (dot, cosine, squared L2 -- whose copy carries |v|^2 as two 8-bit
                             * limbs in up to 121 more dimensions; k <= INNR_MAX_K): the corpus scalar-quantised once with a
                             * single (offset, alpha) -- quantize_u8 with the corpus' own range, the first stage of the two-stage

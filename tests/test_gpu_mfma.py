@@ -168,6 +168,21 @@ def test_knn_mfma_nonfinite_falls_back_to_exact(B, innr):
         assert 17 in oi[:2].tolist() and 0.0 in os_[:2].tolist()  # the NaN-norm row scores 0.0 and leads the finite (negative) cosines
 
 
+def test_knn_auto_builds_the_int8_copy_on_the_fourth_small_call(B, innr):
+    """a caller that keeps sending one query (the reference's own signature in a loop) gets the int8 copy with its fourth AUTO call;
+    answers unchanged"""
+    vb = B.VerticalBatch.generate(150_000, 64, 3)
+    qs = _queries(6, 64, uniform=True)
+    st = innr.KnnStats()
+    engines = []
+    for j in range(6):
+        i1, s1 = B.batch_knn_dot_multi(qs[j:j + 1], vb, 5, stats=st)
+        engines.append(st.engine)
+        e1, es1 = B.batch_knn_dot_multi(qs[j:j + 1], vb, 5, engine=innr.KNN_EXACT)
+        assert np.array_equal(i1, e1) and bits_equal(s1, es1)
+    assert engines == [innr.KNN_EXACT] * 3 + [innr.KNN_MFMA_I8] * 3, engines
+
+
 def test_knn_auto_engine_selection(B, innr):
     """INNR_KNN_AUTO (api.hip, innr_batch_knn_dev): up to 3 queries the exact engine (one HBM-bound corpus pass, no extra memory);
     from 4 queries on the int8 filter for dot / cosine when its corpus copy fits -- and for EVERY batch size once it exists --,
